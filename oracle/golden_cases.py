@@ -1,0 +1,43 @@
+"""TEST INFRASTRUCTURE ONLY.  The golden cases shared by `oracle/make_golden.py` (which runs the
+REAL reference in the build container) and the tests that replay them against the oracle and the
+HIP engine.  Weights are never stored: they are re-created with `torch.manual_seed(seed)` followed
+by construction in the reference's order, and pinned by per-parameter checksums in the fixture."""
+
+TASKS_2HEAD = {
+    "sheet": {"channels": 1, "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss",
+              "loss_kwargs": {"alpha": 0.5, "beta": 0.5}},
+    "normals": {"channels": 3, "activation": "none", "weight": 1, "loss_fn": "MaskedCosineLoss"},
+}
+TASKS_SIGMOID = {
+    "ink": {"channels": 1, "activation": "sigmoid", "weight": 1, "loss_fn": "BCEDiceLoss",
+            "loss_kwargs": {"alpha": 0.5, "beta": 0.5}},
+}
+TASKS_SOFTMAX2 = {
+    "seg": {"channels": 2, "activation": "softmax", "weight": 0.7, "loss_fn": "BCEDiceLoss",
+            "loss_kwargs": {"alpha": 0.5, "beta": 0.5}},
+}
+
+CASES = {
+    # isotropic autoconfig, two task heads (cfg3-style, shrunk): 3 stages [32,64,128], blocks [1,3,4]
+    "auto16_2head": dict(patch=(16, 16, 16), batch=2, in_channels=1, tasks=TASKS_2HEAD,
+                         autoconfigure=True, model_config={}, seed=0, data_seed=1234, train=True),
+    # anisotropic autoconfig (per-axis strides (1,2,2) appear), conv_bias on, eval-mode sigmoid
+    "auto_aniso_bias": dict(patch=(8, 32, 32), batch=1, in_channels=1, tasks=TASKS_SIGMOID,
+                            autoconfigure=True, model_config={"conv_bias": True}, seed=1, data_seed=7,
+                            train=True),
+    # manual topology, 2 input channels, 320-style cap shrunk, softmax 2-class head, weight 0.7
+    "manual_2in": dict(patch=(16, 16, 16), batch=1, in_channels=2, tasks=TASKS_SOFTMAX2,
+                       autoconfigure=False,
+                       model_config={"basic_encoder_block": "BasicBlockD", "basic_decoder_block": "ConvBlock",
+                                     "bottleneck_block": "BasicBlockD", "features_per_stage": [32, 64, 64],
+                                     "num_stages": 3, "n_blocks_per_stage": [1, 2, 2],
+                                     "kernel_sizes": [3, 3, 3], "n_conv_per_stage_decoder": [1, 1],
+                                     "strides": [1, 2, 2]},
+                       seed=2, data_seed=11, train=True),
+}
+
+# parameters whose full gradient is stored in the fixture (small tensors); everything else is pinned
+# through (sum, l2) checksums
+FULL_GRAD_SUFFIXES = ("stem.convs.0.conv.weight", "seg_layers.1.weight", "seg_layers.1.bias",
+                      "seg_layers.2.weight", "seg_layers.2.bias",
+                      "stages.1.blocks.0.skip.1.conv.weight", "transpconvs.0.bias")

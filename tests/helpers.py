@@ -1,0 +1,41 @@
+"""Shared test helpers (test infrastructure)."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import torch
+
+import resenc_oracle as oracle
+from golden_cases import CASES
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    g = {k: z[k] for k in z.files}
+    g["param_names"] = json.loads(str(g["param_names"]))
+    g["state_dict_keys"] = json.loads(str(g["state_dict_keys"]))
+    g["topology"] = json.loads(str(g["topology"]))
+    return g
+
+
+def build_oracle(case_name, dtype=torch.float32):
+    c = CASES[case_name]
+    mgr = oracle.make_mgr(c["patch"], c["tasks"], c["in_channels"], c["batch"], c["autoconfigure"],
+                          c["model_config"])
+    torch.manual_seed(c["seed"])
+    net = oracle.NetworkFromConfig(mgr)
+    return net.to(dtype), c, mgr
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a).double().flatten()
+    b = torch.as_tensor(b).double().flatten()
+    return ((a - b).norm() / b.norm().clamp(min=1e-30)).item()
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
