@@ -1,0 +1,132 @@
+/* rxunet.h -- C ABI of librxunet.so: hand-written CDNA4 (gfx950) kernels for the hot path of the
+ * multi-task 3-D residual-encoder U-Net (reference: /root/reference/builders/, path
+ * NetworkFromConfig.forward + autograd backward).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch's caching allocator);
+ *    nothing here allocates, frees, synchronises or retains pointers after return;
+ *  - every entry point enqueues on `stream` (a hipStream_t passed as void*) and returns
+ *    RX_OK (0) or a negative status; rx_last_error() gives a human-readable reason;
+ *  - activations inside the engine are CHANNELS-LAST (n, z, y, x, c) in the compute dtype
+ *    (RX_F32 parity mode, RX_BF16 / RX_F16 throughput modes); the boundary tensors (input
+ *    image, logits) are NCDHW fp32 exactly as the reference's callers see them
+ *    (train.py:195-204, dataset.py:211-220);
+ *  - parameters and parameter gradients cross the boundary in PyTorch's own layouts
+ *    (Conv3d (Co,Ci,kz,ky,kx), ConvTranspose3d (Ci,Co,kz,ky,kx)), fp32.
+ *
+ * Each entry point names the torch primitive of the reference it replaces (file:line relative to
+ * /root/reference).  The Python binding a maintainer would add is in INTEGRATION.md.
+ */
+#ifndef RXUNET_H
+#define RXUNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RX_OK 0
+#define RX_EINVAL (-1)      /* bad argument (null pointer, non-positive size, misaligned) */
+#define RX_EUNSUPPORTED (-2) /* shape outside what the kernels cover (e.g. channels % 32 != 0) */
+#define RX_ELAUNCH (-3)     /* HIP reported a launch error */
+#define RX_EWORKSPACE (-4)  /* workspace too small */
+
+typedef enum { RX_F32 = 0, RX_BF16 = 1, RX_F16 = 2 } rx_dtype;
+typedef enum { RX_ACT_NONE = 0, RX_ACT_SIGMOID = 1, RX_ACT_SOFTMAX = 2 } rx_head_act;
+
+/* channels-last activation view: element (n,z,y,x,c) lives at
+ * ptr[((n*z_*y_ + ...)*x_ + x)*ld + c]; `ld` >= c lets a view address a channel slice of a wider
+ * buffer (how torch.cat of decoder.py:147 is eliminated). */
+typedef struct {
+  void* ptr;
+  int32_t n, z, y, x, c, ld;
+} rx_act;
+
+int rx_abi_version(void);
+const char* rx_last_error(void);
+int rx_device_arch_ok(void); /* 1 iff the current device is gfx950 */
+
+/* ---- parameter packing ------------------------------------------------------------------ */
+/* Conv3d weight (Co,Ci,T) fp32 -> w_fwd [T][Co][Ci] and w_bwd [T][Ci][Co] (same tap order; the
+ * bwd-data tap table mirrors the offsets instead), both in `dt`.  Either output
+ * may be NULL.  T = kz*ky*kx. */
+int rx_pack_conv_weight(rx_dtype dt, const float* w, int co, int ci, int taps, void* w_fwd, void* w_bwd,
+                        void* stream);
+/* ConvTranspose3d weight (Ci,Co,T) fp32 -> w_fwd [T][Co][Ci], w_bwd [T][Ci][Co] (tap order kept). */
+int rx_pack_convT_weight(rx_dtype dt, const float* w, int ci, int co, int taps, void* w_fwd, void* w_bwd,
+                         void* stream);
+
+/* ---- nn.Conv3d (simple_conv_blocks.py:43-51; kernel per axis in {1,3}, stride per axis in {1,2},
+ *      padding (k-1)/2, dilation 1) ------------------------------------------------------- */
+/* `ws`/`ws_bytes`: optional scratch for split-K (used only for the deep 4^3/8^3 layers whose natural
+ * grid cannot fill 256 CUs); NULL disables split-K.  rx_conv_workspace_hint() is always enough. */
+size_t rx_conv_workspace_hint(void);
+int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, const float* bias, const rx_act* y,
+                  const int32_t kernel[3], const int32_t stride[3], void* ws, size_t ws_bytes, void* stream);
+/* dx (+)= conv_transpose(dy, w): autograd of the above w.r.t. its input */
+int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx,
+                       const int32_t kernel[3], const int32_t stride[3], int accumulate, void* ws,
+                       size_t ws_bytes, void* stream);
+/* dw (Co,Ci,T) fp32 = sum over voxels; workspace from rx_conv3d_bwd_weight_workspace() */
+size_t rx_conv3d_bwd_weight_workspace(const rx_act* x, const rx_act* dy, const int32_t kernel[3]);
+int rx_conv3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw, const int32_t kernel[3],
+                         const int32_t stride[3], void* ws, size_t ws_bytes, void* stream);
+
+/* ---- nn.ConvTranspose3d with kernel == stride, per axis in {1,2} (decoder.py:110-113,146) -- */
+int rx_convT3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, const float* bias, const rx_act* y,
+                   const int32_t stride[3], void* ws, size_t ws_bytes, void* stream);
+int rx_convT3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx,
+                        const int32_t stride[3], int accumulate, void* ws, size_t ws_bytes, void* stream);
+size_t rx_convT3d_bwd_weight_workspace(const rx_act* x, const rx_act* dy, const int32_t stride[3]);
+int rx_convT3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw, const int32_t stride[3],
+                          void* ws, size_t ws_bytes, void* stream);
+
+/* ---- nn.InstanceNorm3d(affine=False, eps) + LeakyReLU(slope) + residual add
+ *      (build_network_from_config.py:172,208-210; resblocks.py:106-114) ------------------- */
+/* stats[n][c] = (mean, rstd) with biased variance; ws: rx_instnorm_stats_workspace() bytes */
+size_t rx_instnorm_stats_workspace(const rx_act* y);
+int rx_instnorm_stats(rx_dtype dt, const rx_act* y, float eps, float* stats, void* ws, size_t ws_bytes,
+                      void* stream);
+/* out = lrelu_slope( (y-mean)*rstd + residual ); residual may be NULL; slope = 1 -> no activation */
+int rx_instnorm_act_fwd(rx_dtype dt, const rx_act* y, const float* stats, const rx_act* residual,
+                        const rx_act* out, float slope, void* stream);
+/* g = dL/dout; `out` supplies the sign for the LeakyReLU mask (NULL when slope == 1).
+ * dy = dL/dy; d_residual (optional) receives (or accumulates) g*mask.  ws as for stats. */
+int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out,
+                        float slope, const rx_act* dy, const rx_act* d_residual, int accumulate_residual,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* ---- nn.AvgPool3d(kernel=stride, per axis in {1,2}) (resblocks.py:95) -------------------- */
+int rx_avgpool_fwd(rx_dtype dt, const rx_act* x, const rx_act* y, const int32_t stride[3], void* stream);
+int rx_avgpool_bwd(rx_dtype dt, const rx_act* dy, const rx_act* dx, const int32_t stride[3], int accumulate,
+                   void* stream);
+
+/* ---- stem: first Conv3d on the NCDHW fp32 image, Cin <= 4 (encoder.py:84) ---------------- */
+int rx_stem_conv_fwd(rx_dtype dt, const float* x_ncdhw, int n, int cin, int z, int y, int x, const float* w,
+                     const float* bias, const rx_act* out, const int32_t kernel[3], void* stream);
+size_t rx_stem_conv_bwd_weight_workspace(int cin, int cout, int taps);
+int rx_stem_conv_bwd_weight(rx_dtype dt, const float* x_ncdhw, int n, int cin, int z, int y, int x,
+                            const rx_act* dy, float* dw, const int32_t kernel[3], void* ws, size_t ws_bytes,
+                            void* stream);
+
+/* ---- task head: Conv3d 1x1x1 with bias to K <= 8 channels, NCDHW fp32 logits, optional
+ *      eval-mode activation (decoder.py:131,151-152; build_network_from_config.py:320-323) ---- */
+int rx_head_fwd(rx_dtype dt, const rx_act* x, const float* w, const float* b, int k, float* out_ncdhw,
+                int act, void* stream);
+size_t rx_head_bwd_workspace(const rx_act* x, int k);
+int rx_head_bwd(rx_dtype dt, const float* dout_ncdhw, const rx_act* x, const float* w, int k, const rx_act* dx,
+                float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- per-channel sum over (n, voxels): bias gradients ----------------------------------- */
+size_t rx_channel_sum_workspace(const rx_act* x);
+int rx_channel_sum(rx_dtype dt, const rx_act* x, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- fused train-step losses on NCDHW fp32 logits (training/losses/losses.py) ----------- */
+/* reserved for a later round; see DESIGN.md "next" */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RXUNET_H */

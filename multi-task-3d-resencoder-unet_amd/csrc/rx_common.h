@@ -1,0 +1,150 @@
+// rx_common.h -- shared device/host helpers for librxunet (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/rxunet.h"
+
+#define RX_WAVE 64
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// ---- error plumbing (host) -----------------------------------------------------------------
+void rx_set_error(const char* fmt, ...);
+#define RX_FAIL(code, ...)      \
+  do {                          \
+    rx_set_error(__VA_ARGS__);  \
+    return (code);              \
+  } while (0)
+#define RX_CHECK_LAUNCH(name)                                                  \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess) RX_FAIL(RX_ELAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---- element traits ------------------------------------------------------------------------
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static constexpr int PER16 = 4;  // elements per 16-byte vector
+  __device__ static inline float to_f(float v) { return v; }
+  __device__ static inline float from_f(float v) { return v; }
+};
+template <>
+struct Elem<bf16_t> {
+  static constexpr int PER16 = 8;
+  __device__ static inline float to_f(bf16_t v) { return (float)v; }
+  __device__ static inline bf16_t from_f(float v) { return (bf16_t)v; }
+};
+template <>
+struct Elem<f16_t> {
+  static constexpr int PER16 = 8;
+  __device__ static inline float to_f(f16_t v) { return (float)v; }
+  __device__ static inline f16_t from_f(float v) { return (f16_t)v; }
+};
+
+// 16-byte vector of T, convertible to/from floats
+template <typename T>
+struct alignas(16) Vec16 {
+  T v[Elem<T>::PER16];
+};
+
+template <typename T>
+__device__ inline Vec16<T> ld16(const T* p) {
+  Vec16<T> r;
+  *reinterpret_cast<u32x4*>(&r) = *reinterpret_cast<const u32x4*>(p);
+  return r;
+}
+template <typename T>
+__device__ inline void st16(T* p, const Vec16<T>& r) {
+  *reinterpret_cast<u32x4*>(p) = *reinterpret_cast<const u32x4*>(&r);
+}
+template <typename T>
+__device__ inline Vec16<T> zero16() {
+  Vec16<T> r;
+  *reinterpret_cast<u32x4*>(&r) = u32x4{0u, 0u, 0u, 0u};
+  return r;
+}
+
+// ---- wave / block reductions ---------------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- dtype dispatch ------------------------------------------------------------------------
+#define RX_DISPATCH_DTYPE(dt, T, ...)                          \
+  switch (dt) {                                                \
+    case RX_F32: {                                             \
+      using T = float;                                         \
+      __VA_ARGS__;                                             \
+    } break;                                                   \
+    case RX_BF16: {                                            \
+      using T = bf16_t;                                        \
+      __VA_ARGS__;                                             \
+    } break;                                                   \
+    case RX_F16: {                                             \
+      using T = f16_t;                                         \
+      __VA_ARGS__;                                             \
+    } break;                                                   \
+    default:                                                   \
+      RX_FAIL(RX_EINVAL, "unknown dtype %d", (int)(dt));       \
+  }
+
+static inline size_t rx_dtype_size(int dt) { return dt == RX_F32 ? 4 : 2; }
+static inline size_t rx_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static inline long rx_act_voxels(const rx_act* a) { return (long)a->z * a->y * a->x; }
+static inline bool rx_act_ok(const rx_act* a) {
+  return a && a->ptr && a->n > 0 && a->z > 0 && a->y > 0 && a->x > 0 && a->c > 0 && a->ld >= a->c;
+}
+
+// ---- tap tables and MFMA wrappers shared by the implicit-GEMM and weight-gradient kernels ------
+struct RxTap {
+  int8_t dz, dy, dx;
+  uint8_t w;
+};
+
+// one 32x32 accumulator update from two 16-byte operand fragments (lane = row/col (lane&31),
+// k-half (lane>>5)): 16 k-values for 16-bit types, 8 for fp32 (4 exact-fp32 MFMAs).
+template <typename T>
+struct Mma;
+template <>
+struct Mma<bf16_t> {
+  __device__ static inline void run(f32x16& c, const u32x4& a, const u32x4& b) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct Mma<f16_t> {
+  __device__ static inline void run(f32x16& c, const u32x4& a, const u32x4& b) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct Mma<float> {
+  __device__ static inline void run(f32x16& c, const u32x4& a, const u32x4& b) {
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[j], c, 0, 0, 0);
+  }
+};

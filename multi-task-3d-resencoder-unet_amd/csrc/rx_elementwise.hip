@@ -1,0 +1,988 @@
+// rx_elementwise.hip -- HBM-bound kernels of the hot path: InstanceNorm statistics, the fused
+// InstanceNorm-apply + LeakyReLU + residual-add forward / backward, AvgPool, per-channel sums,
+// the 1x1x1 task head, the Cin<=4 stem convolution and the weight packers.
+//
+// All activations are channels-last; every thread moves 16-byte channel vectors (8 bf16 / 4 f32),
+// adjacent lanes touch adjacent addresses, per-(n,c) reductions are deterministic two-stage
+// reductions (per-block partials in a workspace, finalised in fp64) -- no float atomics.
+#include <stdarg.h>
+
+#include "rx_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// error string
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void rx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* rx_last_error(void) { return g_err; }
+extern "C" int rx_abi_version(void) { return 1; }
+extern "C" int rx_device_arch_ok(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+  return strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// column (per-(n,c)) reductions: shared machinery
+// ---------------------------------------------------------------------------------------------
+// Work split: grid = (nchunks, N).  A block owns voxels [chunk*chunk_vox, ...) of sample n.
+// thread -> (vl = tid / CV, cv = tid % CV): channel vector cv of voxels vl, vl+VP, ...
+// Partials: partial[((n*nchunks + chunk)*NACC + a)*C + c].
+struct ReducePlan {
+  int nchunks, chunk_vox;
+};
+static inline ReducePlan rx_reduce_plan(long V, int C, int per16) {
+  int CV = C / per16;
+  int VP = 256 / CV;
+  if (VP < 1) VP = 1;
+  long nch = V / 2048;
+  if (nch < 1) nch = 1;
+  if (nch > 1024) nch = 1024;
+  long cvx = (V + nch - 1) / nch;
+  cvx = (cvx + VP - 1) / VP * VP;
+  nch = (V + cvx - 1) / cvx;
+  ReducePlan p;
+  p.nchunks = (int)nch;
+  p.chunk_vox = (int)cvx;
+  return p;
+}
+static inline size_t rx_reduce_ws_bytes(int N, long V, int C, int nacc) {
+  // sized for the finest element type (per16 = 4 gives the most chunks)
+  ReducePlan p = rx_reduce_plan(V, C, 4);
+  ReducePlan q = rx_reduce_plan(V, C, 8);
+  int nch = p.nchunks > q.nchunks ? p.nchunks : q.nchunks;
+  return (size_t)N * nch * nacc * C * sizeof(float) + 256;
+}
+
+template <typename T, int NACC, typename Op>
+__global__ __launch_bounds__(256) void colreduce_kernel(Op op, int V, int C, int chunk_vox, float* __restrict__ partial) {
+  constexpr int P = Elem<T>::PER16;
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [NACC][VP][C]
+  const int CV = C / P;
+  const int VP = 256 / CV > 0 ? 256 / CV : 1;
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  float acc[NACC][P];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int j = 0; j < P; ++j) acc[a][j] = 0.f;
+  const int v_begin = chunk * chunk_vox;
+  const int v_end = min(V, v_begin + chunk_vox);
+  // CV may exceed 256 only if C > 256*P, rejected on the host
+  const int vl = tid / CV, cv = tid - vl * CV;
+  if (vl < VP) {
+    for (int v = v_begin + vl; v < v_end; v += VP) op.accumulate(n, v, cv * P, acc);
+  }
+  if (vl < VP) {
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int j = 0; j < P; ++j) sm[(a * VP + vl) * C + cv * P + j] = acc[a][j];
+  }
+  __syncthreads();
+  for (int i = tid; i < NACC * C; i += 256) {
+    int a = i / C, c = i - a * C;
+    float s = 0.f;
+    for (int r = 0; r < VP; ++r) s += sm[(a * VP + r) * C + c];
+    partial[((size_t)(n * gridDim.x + chunk) * NACC + a) * C + c] = s;
+  }
+}
+
+// finalize modes
+enum { FIN_STATS = 0, FIN_MEAN2 = 1, FIN_SUM_OVER_N = 2 };
+// FIN_STATS: out[n][c] = (mean, rstd) from (sum, sumsq);  FIN_MEAN2: out[n][c] = (s0/V, s1/V);
+// FIN_SUM_OVER_N: out[a][c] = sum over n and chunks (NACC planes)
+__global__ void colreduce_finalize(const float* __restrict__ partial, int N, int nchunks, int nacc, int C, double V,
+                                   float eps, int mode, float* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mode == FIN_SUM_OVER_N) {
+    if (i >= nacc * C) return;
+    int a = i / C, c = i - a * C;
+    double s = 0.0;
+    for (int n = 0; n < N; ++n)
+      for (int k = 0; k < nchunks; ++k) s += (double)partial[((size_t)(n * nchunks + k) * nacc + a) * C + c];
+    out[i] = (float)s;
+    return;
+  }
+  if (i >= N * C) return;
+  int n = i / C, c = i - n * C;
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = 0; k < nchunks; ++k) {
+    const float* p = partial + ((size_t)(n * nchunks + k) * 2) * C + c;
+    s0 += (double)p[0];
+    s1 += (double)p[C];
+  }
+  if (mode == FIN_STATS) {
+    double mean = s0 / V;
+    double var = s1 / V - mean * mean;
+    if (var < 0.0) var = 0.0;
+    out[2 * i] = (float)mean;
+    out[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  } else {
+    out[2 * i] = (float)(s0 / V);
+    out[2 * i + 1] = (float)(s1 / V);
+  }
+}
+
+template <typename T>
+struct ActView {
+  const T* ptr;
+  long sample_stride;  // elements
+  int ld;
+  __device__ inline const T* at(int n, int v, int c) const { return ptr + n * sample_stride + (long)v * ld + c; }
+};
+template <typename T>
+static inline ActView<T> make_view(const rx_act* a) {
+  ActView<T> r;
+  r.ptr = (const T*)a->ptr;
+  r.ld = a->ld;
+  r.sample_stride = rx_act_voxels(a) * (long)a->ld;
+  return r;
+}
+
+// ---- InstanceNorm statistics ----------------------------------------------------------------
+template <typename T>
+struct StatsOp {
+  ActView<T> y;
+  __device__ inline void accumulate(int n, int v, int c0, float (&acc)[2][Elem<T>::PER16]) const {
+    Vec16<T> x = ld16(y.at(n, v, c0));
+#pragma unroll
+    for (int j = 0; j < Elem<T>::PER16; ++j) {
+      float f = Elem<T>::to_f(x.v[j]);
+      acc[0][j] += f;
+      acc[1][j] += f * f;
+    }
+  }
+};
+
+static int check_vec_channels(const rx_act* a, int dt, const char* who) {
+  int per16 = dt == RX_F32 ? 4 : 8;
+  if (!rx_act_ok(a)) RX_FAIL(RX_EINVAL, "%s: bad activation descriptor", who);
+  if (a->c % per16 || a->ld % per16 || ((uintptr_t)a->ptr & 15)) RX_FAIL(RX_EUNSUPPORTED, "%s: channels/ld/ptr must be 16-byte multiples (c=%d ld=%d)", who, a->c, a->ld);
+  if (a->c / per16 > 256) RX_FAIL(RX_EUNSUPPORTED, "%s: too many channels (%d)", who, a->c);
+  return RX_OK;
+}
+
+extern "C" size_t rx_instnorm_stats_workspace(const rx_act* y) {
+  if (!rx_act_ok(y)) return 0;
+  return rx_reduce_ws_bytes(y->n, rx_act_voxels(y), y->c, 2);
+}
+
+extern "C" int rx_instnorm_stats(rx_dtype dt, const rx_act* y, float eps, float* stats, void* ws, size_t ws_bytes,
+                                 void* stream) {
+  int rc = check_vec_channels(y, dt, "rx_instnorm_stats");
+  if (rc) return rc;
+  if (!stats || !ws) RX_FAIL(RX_EINVAL, "rx_instnorm_stats: null stats/workspace");
+  if (ws_bytes < rx_instnorm_stats_workspace(y)) RX_FAIL(RX_EWORKSPACE, "rx_instnorm_stats: workspace too small");
+  const long V = rx_act_voxels(y);
+  hipStream_t st = (hipStream_t)stream;
+  RX_DISPATCH_DTYPE(dt, T, {
+    constexpr int P = Elem<T>::PER16;
+    ReducePlan p = rx_reduce_plan(V, y->c, P);
+    int CV = y->c / P, VP = 256 / CV;
+    StatsOp<T> op{make_view<T>(y)};
+    size_t lds = (size_t)2 * VP * y->c * sizeof(float);
+    hipLaunchKernelGGL((colreduce_kernel<T, 2, StatsOp<T>>), dim3(p.nchunks, y->n), dim3(256), lds, st, op, (int)V, y->c,
+                       p.chunk_vox, (float*)ws);
+    int tot = y->n * y->c;
+    hipLaunchKernelGGL(colreduce_finalize, dim3((tot + 255) / 256), dim3(256), 0, st, (const float*)ws, y->n, p.nchunks, 2,
+                       y->c, (double)V, eps, (int)FIN_STATS, stats);
+  });
+  RX_CHECK_LAUNCH("rx_instnorm_stats");
+  return RX_OK;
+}
+
+// ---- per-channel sum over (n, voxels) -------------------------------------------------------
+template <typename T>
+struct SumOp {
+  ActView<T> x;
+  __device__ inline void accumulate(int n, int v, int c0, float (&acc)[1][Elem<T>::PER16]) const {
+    Vec16<T> a = ld16(x.at(n, v, c0));
+#pragma unroll
+    for (int j = 0; j < Elem<T>::PER16; ++j) acc[0][j] += Elem<T>::to_f(a.v[j]);
+  }
+};
+extern "C" size_t rx_channel_sum_workspace(const rx_act* x) {
+  if (!rx_act_ok(x)) return 0;
+  return rx_reduce_ws_bytes(x->n, rx_act_voxels(x), x->c, 1);
+}
+extern "C" int rx_channel_sum(rx_dtype dt, const rx_act* x, float* out, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_vec_channels(x, dt, "rx_channel_sum");
+  if (rc) return rc;
+  if (!out || !ws) RX_FAIL(RX_EINVAL, "rx_channel_sum: null out/workspace");
+  if (ws_bytes < rx_channel_sum_workspace(x)) RX_FAIL(RX_EWORKSPACE, "rx_channel_sum: workspace too small");
+  const long V = rx_act_voxels(x);
+  hipStream_t st = (hipStream_t)stream;
+  RX_DISPATCH_DTYPE(dt, T, {
+    constexpr int P = Elem<T>::PER16;
+    ReducePlan p = rx_reduce_plan(V, x->c, P);
+    int CV = x->c / P, VP = 256 / CV;
+    SumOp<T> op{make_view<T>(x)};
+    size_t lds = (size_t)VP * x->c * sizeof(float);
+    hipLaunchKernelGGL((colreduce_kernel<T, 1, SumOp<T>>), dim3(p.nchunks, x->n), dim3(256), lds, st, op, (int)V, x->c,
+                       p.chunk_vox, (float*)ws);
+    hipLaunchKernelGGL(colreduce_finalize, dim3((x->c + 255) / 256), dim3(256), 0, st, (const float*)ws, x->n, p.nchunks, 1,
+                       x->c, (double)V, 0.f, (int)FIN_SUM_OVER_N, out);
+  });
+  RX_CHECK_LAUNCH("rx_channel_sum");
+  return RX_OK;
+}
+
+// ---- fused InstanceNorm-apply + residual + LeakyReLU forward -------------------------------
+// grid = (G, N); a thread keeps its channel vector fixed (G*256 % CV == 0) so mean/rstd live in
+// registers for the whole sweep.
+template <typename T, bool HAS_RES>
+__global__ __launch_bounds__(256) void in_act_fwd_kernel(const T* __restrict__ y, int ldy, long sy, const float* __restrict__ stats,
+                                                         const T* __restrict__ res, int ldr, long sr, T* __restrict__ out, int ldo,
+                                                         long so, int V, int C, float slope) {
+  constexpr int P = Elem<T>::PER16;
+  const int CV = C / P;
+  const int n = blockIdx.y;
+  const long total = (long)V * CV;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long step = (long)gridDim.x * 256;
+  const int cv = (int)(i % CV);
+  float mean[P], rstd[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    mean[j] = stats[2 * ((size_t)n * C + cv * P + j)];
+    rstd[j] = stats[2 * ((size_t)n * C + cv * P + j) + 1];
+  }
+  const T* yn = y + n * sy;
+  const T* rn = HAS_RES ? res + n * sr : nullptr;
+  T* on = out + n * so;
+  for (; i < total; i += step) {
+    long v = i / CV;
+    Vec16<T> a = ld16(yn + v * ldy + cv * P);
+    Vec16<T> r;
+    if (HAS_RES) r = ld16(rn + v * ldr + cv * P);
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      float f = (Elem<T>::to_f(a.v[j]) - mean[j]) * rstd[j];
+      if (HAS_RES) f += Elem<T>::to_f(r.v[j]);
+      f = f > 0.f ? f : f * slope;
+      o.v[j] = Elem<T>::from_f(f);
+    }
+    st16(on + v * ldo + cv * P, o);
+  }
+}
+
+static inline int sweep_grid(long total_vec, int CV) {
+  // number of blocks G with (G*256) % CV == 0, so that every thread keeps one channel vector
+  int g = CV, d = 256;
+  while (g % 2 == 0 && d > 1) {
+    g /= 2;
+    d /= 2;
+  }
+  long want = (total_vec + 256 * 8 - 1) / (256 * 8);
+  if (want < 1) want = 1;
+  if (want > 2048) want = 2048;
+  long G = (want + g - 1) / g * g;
+  return (int)G;
+}
+
+static int same_geom(const rx_act* a, const rx_act* b) {
+  return a->n == b->n && a->z == b->z && a->y == b->y && a->x == b->x && a->c == b->c;
+}
+
+extern "C" int rx_instnorm_act_fwd(rx_dtype dt, const rx_act* y, const float* stats, const rx_act* residual,
+                                   const rx_act* out, float slope, void* stream) {
+  int rc = check_vec_channels(y, dt, "rx_instnorm_act_fwd(y)");
+  if (rc) return rc;
+  rc = check_vec_channels(out, dt, "rx_instnorm_act_fwd(out)");
+  if (rc) return rc;
+  if (!stats || !same_geom(y, out)) RX_FAIL(RX_EINVAL, "rx_instnorm_act_fwd: geometry mismatch / null stats");
+  if (residual) {
+    rc = check_vec_channels(residual, dt, "rx_instnorm_act_fwd(residual)");
+    if (rc) return rc;
+    if (!same_geom(y, residual)) RX_FAIL(RX_EINVAL, "rx_instnorm_act_fwd: residual geometry mismatch");
+  }
+  const long V = rx_act_voxels(y);
+  hipStream_t st = (hipStream_t)stream;
+  RX_DISPATCH_DTYPE(dt, T, {
+    constexpr int P = Elem<T>::PER16;
+    int CV = y->c / P;
+    int G = sweep_grid(V * CV, CV);
+    if (residual)
+      hipLaunchKernelGGL((in_act_fwd_kernel<T, true>), dim3(G, y->n), dim3(256), 0, st, (const T*)y->ptr, y->ld, V * y->ld, stats,
+                         (const T*)residual->ptr, residual->ld, V * residual->ld, (T*)out->ptr, out->ld, V * out->ld, (int)V,
+                         y->c, slope);
+    else
+      hipLaunchKernelGGL((in_act_fwd_kernel<T, false>), dim3(G, y->n), dim3(256), 0, st, (const T*)y->ptr, y->ld, V * y->ld, stats,
+                         (const T*)nullptr, 0, 0L, (T*)out->ptr, out->ld, V * out->ld, (int)V, y->c, slope);
+  });
+  RX_CHECK_LAUNCH("rx_instnorm_act_fwd");
+  return RX_OK;
+}
+
+// ---- fused backward --------------------------------------------------------------------------
+// g' = g * (out > 0 ? 1 : slope);  xhat = (y-mean)*rstd
+// pass 1: m1 = mean(g'), m2 = mean(g'*xhat) per (n,c);  pass 2: dy = rstd*(g' - m1 - xhat*m2)
+template <typename T>
+struct InBwdOp {
+  ActView<T> g, y, out;
+  const float* stats;
+  int C;
+  float slope;
+  bool use_mask;
+  __device__ inline void accumulate(int n, int v, int c0, float (&acc)[2][Elem<T>::PER16]) const {
+    constexpr int P = Elem<T>::PER16;
+    Vec16<T> gv = ld16(g.at(n, v, c0));
+    Vec16<T> yv = ld16(y.at(n, v, c0));
+    Vec16<T> ov;
+    if (use_mask) ov = ld16(out.at(n, v, c0));
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      float gg = Elem<T>::to_f(gv.v[j]);
+      if (use_mask && !(Elem<T>::to_f(ov.v[j]) > 0.f)) gg *= slope;
+      float mean = stats[2 * ((size_t)n * C + c0 + j)], rstd = stats[2 * ((size_t)n * C + c0 + j) + 1];
+      float xh = (Elem<T>::to_f(yv.v[j]) - mean) * rstd;
+      acc[0][j] += gg;
+      acc[1][j] += gg * xh;
+    }
+  }
+};
+
+template <typename T, bool HAS_DRES, bool ACC_DRES>
+__global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restrict__ g, int ldg, long sg, const T* __restrict__ y, int ldy,
+                                                               long sy, const T* __restrict__ out, int ldo, long so,
+                                                               const float* __restrict__ stats, const float* __restrict__ m12,
+                                                               T* __restrict__ dy, int lddy, long sdy, T* __restrict__ dres, int lddr,
+                                                               long sdr, int V, int C, float slope, int use_mask) {
+  constexpr int P = Elem<T>::PER16;
+  const int CV = C / P;
+  const int n = blockIdx.y;
+  const long total = (long)V * CV;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long step = (long)gridDim.x * 256;
+  const int cv = (int)(i % CV);
+  float mean[P], rstd[P], m1[P], m2[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    size_t k = (size_t)n * C + cv * P + j;
+    mean[j] = stats[2 * k];
+    rstd[j] = stats[2 * k + 1];
+    m1[j] = m12[2 * k];
+    m2[j] = m12[2 * k + 1];
+  }
+  for (; i < total; i += step) {
+    long v = i / CV;
+    Vec16<T> gv = ld16(g + n * sg + v * ldg + cv * P);
+    Vec16<T> yv = ld16(y + n * sy + v * ldy + cv * P);
+    Vec16<T> ov;
+    if (use_mask) ov = ld16(out + n * so + v * ldo + cv * P);
+    Vec16<T> dv, rv;
+    if (HAS_DRES && ACC_DRES) rv = ld16(dres + n * sdr + v * lddr + cv * P);
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      float gg = Elem<T>::to_f(gv.v[j]);
+      if (use_mask && !(Elem<T>::to_f(ov.v[j]) > 0.f)) gg *= slope;
+      float xh = (Elem<T>::to_f(yv.v[j]) - mean[j]) * rstd[j];
+      dv.v[j] = Elem<T>::from_f(rstd[j] * (gg - m1[j] - xh * m2[j]));
+      if (HAS_DRES) {
+        float r = gg;
+        if (ACC_DRES) r += Elem<T>::to_f(rv.v[j]);
+        rv.v[j] = Elem<T>::from_f(r);
+      }
+    }
+    st16(dy + n * sdy + v * lddy + cv * P, dv);
+    if (HAS_DRES) st16(dres + n * sdr + v * lddr + cv * P, rv);
+  }
+}
+
+#define RX_LAUNCH_APPLY(HD, AD)                                                                                                   \
+  hipLaunchKernelGGL((in_act_bwd_apply_kernel<T, HD, AD>), dim3(G, N), dim3(256), 0, st, (const T*)g->ptr, g->ld, V * g->ld,     \
+                     (const T*)y->ptr, y->ld, V * y->ld, outp, ldo, V * ldo, stats, (const float*)m12, (T*)dy->ptr, dy->ld,       \
+                     V * dy->ld, d_residual ? (T*)d_residual->ptr : (T*)nullptr, d_residual ? d_residual->ld : 0,                 \
+                     d_residual ? V * d_residual->ld : 0L, (int)V, C, slope, (int)use_mask)
+
+extern "C" int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out,
+                                   float slope, const rx_act* dy, const rx_act* d_residual, int accumulate_residual, void* ws,
+                                   size_t ws_bytes, void* stream) {
+  int rc;
+  if ((rc = check_vec_channels(g, dt, "rx_instnorm_act_bwd(g)"))) return rc;
+  if ((rc = check_vec_channels(y, dt, "rx_instnorm_act_bwd(y)"))) return rc;
+  if ((rc = check_vec_channels(dy, dt, "rx_instnorm_act_bwd(dy)"))) return rc;
+  const bool use_mask = slope != 1.0f;
+  if (use_mask) {
+    if (!out) RX_FAIL(RX_EINVAL, "rx_instnorm_act_bwd: `out` is required when slope != 1");
+    if ((rc = check_vec_channels(out, dt, "rx_instnorm_act_bwd(out)"))) return rc;
+    if (!same_geom(y, out)) RX_FAIL(RX_EINVAL, "rx_instnorm_act_bwd: out geometry mismatch");
+  }
+  if (d_residual) {
+    if ((rc = check_vec_channels(d_residual, dt, "rx_instnorm_act_bwd(d_residual)"))) return rc;
+    if (!same_geom(y, d_residual)) RX_FAIL(RX_EINVAL, "rx_instnorm_act_bwd: d_residual geometry mismatch");
+  }
+  if (!stats || !ws || !same_geom(y, g) || !same_geom(y, dy)) RX_FAIL(RX_EINVAL, "rx_instnorm_act_bwd: bad arguments");
+  const long V = rx_act_voxels(y);
+  const int N = y->n, C = y->c;
+  size_t need = rx_reduce_ws_bytes(N, V, C, 2) + (size_t)N * C * 2 * sizeof(float);
+  if (ws_bytes < need) RX_FAIL(RX_EWORKSPACE, "rx_instnorm_act_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
+  float* partial = (float*)ws;
+  float* m12 = (float*)((char*)ws + rx_align_up(rx_reduce_ws_bytes(N, V, C, 2) - 256, 256));
+  hipStream_t st = (hipStream_t)stream;
+  RX_DISPATCH_DTYPE(dt, T, {
+    constexpr int P = Elem<T>::PER16;
+    ReducePlan p = rx_reduce_plan(V, C, P);
+    int CV = C / P, VP = 256 / CV;
+    InBwdOp<T> op{make_view<T>(g), make_view<T>(y), use_mask ? make_view<T>(out) : make_view<T>(y), stats, C, slope, use_mask};
+    size_t lds = (size_t)2 * VP * C * sizeof(float);
+    hipLaunchKernelGGL((colreduce_kernel<T, 2, InBwdOp<T>>), dim3(p.nchunks, N), dim3(256), lds, st, op, (int)V, C, p.chunk_vox,
+                       partial);
+    hipLaunchKernelGGL(colreduce_finalize, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float*)partial, N, p.nchunks, 2, C,
+                       (double)V, 0.f, (int)FIN_MEAN2, m12);
+    int G = sweep_grid(V * CV, CV);
+    const T* outp = use_mask ? (const T*)out->ptr : nullptr;
+    int ldo = use_mask ? out->ld : 0;
+    if (!d_residual)
+      RX_LAUNCH_APPLY(false, false);
+    else if (accumulate_residual)
+      RX_LAUNCH_APPLY(true, true);
+    else
+      RX_LAUNCH_APPLY(true, false);
+  });
+  RX_CHECK_LAUNCH("rx_instnorm_act_bwd");
+  return RX_OK;
+}
+
+// ---- AvgPool (kernel = stride, per axis 1 or 2) ---------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, int ldx, long sx, T* __restrict__ y, int ldy, long sy,
+                                                          int Zo, int Yo, int Xo, int Yi, int Xi, int C, int fz, int fy, int fx) {
+  constexpr int P = Elem<T>::PER16;
+  const int CV = C / P;
+  const int n = blockIdx.y;
+  const long total = (long)Zo * Yo * Xo * CV;
+  const float inv = 1.f / (float)(fz * fy * fx);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int cv = (int)(i % CV);
+    long vo = i / CV;
+    int xo = (int)(vo % Xo);
+    int yo = (int)((vo / Xo) % Yo);
+    int zo = (int)(vo / ((long)Xo * Yo));
+    float acc[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) acc[j] = 0.f;
+    for (int a = 0; a < fz; ++a)
+      for (int b = 0; b < fy; ++b)
+        for (int c = 0; c < fx; ++c) {
+          long vi = ((long)(zo * fz + a) * Yi + (yo * fy + b)) * Xi + (xo * fx + c);
+          Vec16<T> t = ld16(x + n * sx + vi * ldx + cv * P);
+#pragma unroll
+          for (int j = 0; j < P; ++j) acc[j] += Elem<T>::to_f(t.v[j]);
+        }
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < P; ++j) o.v[j] = Elem<T>::from_f(acc[j] * inv);
+    st16(y + n * sy + vo * ldy + cv * P, o);
+  }
+}
+
+template <typename T, bool ACC>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, int ldy, long sy, T* __restrict__ dx, int ldx, long sx,
+                                                          int Zi, int Yi, int Xi, int Yo, int Xo, int C, int fz, int fy, int fx) {
+  constexpr int P = Elem<T>::PER16;
+  const int CV = C / P;
+  const int n = blockIdx.y;
+  const long total = (long)Zi * Yi * Xi * CV;
+  const float inv = 1.f / (float)(fz * fy * fx);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int cv = (int)(i % CV);
+    long vi = i / CV;
+    int xi = (int)(vi % Xi);
+    int yi = (int)((vi / Xi) % Yi);
+    int zi = (int)(vi / ((long)Xi * Yi));
+    long vo = ((long)(zi / fz) * Yo + (yi / fy)) * Xo + (xi / fx);
+    Vec16<T> t = ld16(dy + n * sy + vo * ldy + cv * P);
+    Vec16<T> o;
+    if (ACC) o = ld16(dx + n * sx + vi * ldx + cv * P);
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      float f = Elem<T>::to_f(t.v[j]) * inv;
+      if (ACC) f += Elem<T>::to_f(o.v[j]);
+      o.v[j] = Elem<T>::from_f(f);
+    }
+    st16(dx + n * sx + vi * ldx + cv * P, o);
+  }
+}
+
+static int check_pool(const rx_act* big, const rx_act* small, const int32_t f[3], const char* who) {
+  for (int i = 0; i < 3; ++i)
+    if (f[i] != 1 && f[i] != 2) RX_FAIL(RX_EUNSUPPORTED, "%s: pool factor must be 1 or 2", who);
+  if (big->n != small->n || big->c != small->c || big->z != small->z * f[0] || big->y != small->y * f[1] || big->x != small->x * f[2])
+    RX_FAIL(RX_EINVAL, "%s: geometry mismatch (%d,%d,%d)/(%d,%d,%d)", who, big->z, big->y, big->x, small->z, small->y, small->x);
+  return RX_OK;
+}
+
+extern "C" int rx_avgpool_fwd(rx_dtype dt, const rx_act* x, const rx_act* y, const int32_t stride[3], void* stream) {
+  int rc;
+  if ((rc = check_vec_channels(x, dt, "rx_avgpool_fwd(x)"))) return rc;
+  if ((rc = check_vec_channels(y, dt, "rx_avgpool_fwd(y)"))) return rc;
+  if ((rc = check_pool(x, y, stride, "rx_avgpool_fwd"))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  RX_DISPATCH_DTYPE(dt, T, {
+    constexpr int P = Elem<T>::PER16;
+    long total = rx_act_voxels(y) * (y->c / P);
+    int G = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL((avgpool_fwd_kernel<T>), dim3(G, x->n), dim3(256), 0, st, (const T*)x->ptr, x->ld, rx_act_voxels(x) * x->ld,
+                       (T*)y->ptr, y->ld, rx_act_voxels(y) * y->ld, y->z, y->y, y->x, x->y, x->x, x->c, stride[0], stride[1], stride[2]);
+  });
+  RX_CHECK_LAUNCH("rx_avgpool_fwd");
+  return RX_OK;
+}
+
+extern "C" int rx_avgpool_bwd(rx_dtype dt, const rx_act* dy, const rx_act* dx, const int32_t stride[3], int accumulate,
+                              void* stream) {
+  int rc;
+  if ((rc = check_vec_channels(dx, dt, "rx_avgpool_bwd(dx)"))) return rc;
+  if ((rc = check_vec_channels(dy, dt, "rx_avgpool_bwd(dy)"))) return rc;
+  if ((rc = check_pool(dx, dy, stride, "rx_avgpool_bwd"))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  RX_DISPATCH_DTYPE(dt, T, {
+    constexpr int P = Elem<T>::PER16;
+    long total = rx_act_voxels(dx) * (dx->c / P);
+    int G = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (accumulate)
+      hipLaunchKernelGGL((avgpool_bwd_kernel<T, true>), dim3(G, dx->n), dim3(256), 0, st, (const T*)dy->ptr, dy->ld,
+                         rx_act_voxels(dy) * dy->ld, (T*)dx->ptr, dx->ld, rx_act_voxels(dx) * dx->ld, dx->z, dx->y, dx->x, dy->y,
+                         dy->x, dx->c, stride[0], stride[1], stride[2]);
+    else
+      hipLaunchKernelGGL((avgpool_bwd_kernel<T, false>), dim3(G, dx->n), dim3(256), 0, st, (const T*)dy->ptr, dy->ld,
+                         rx_act_voxels(dy) * dy->ld, (T*)dx->ptr, dx->ld, rx_act_voxels(dx) * dx->ld, dx->z, dx->y, dx->x, dy->y,
+                         dy->x, dx->c, stride[0], stride[1], stride[2]);
+  });
+  RX_CHECK_LAUNCH("rx_avgpool_bwd");
+  return RX_OK;
+}
+
+// ---- task head: 1x1x1 conv with bias to K <= 8 channels -------------------------------------
+#define RX_HEAD_MAXK 8
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, int ldx, long sx, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int K, float* __restrict__ out, int V, int C, int act) {
+  constexpr int P = Elem<T>::PER16;
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [K][C]
+  for (int i = threadIdx.x; i < K * C; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const int n = blockIdx.y;
+  const int CV = C / P;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long)gridDim.x * 256) {
+    float acc[RX_HEAD_MAXK];
+#pragma unroll
+    for (int k = 0; k < RX_HEAD_MAXK; ++k) acc[k] = k < K ? b[k] : 0.f;
+    const T* xp = x + n * sx + v * ldx;
+    for (int cv = 0; cv < CV; ++cv) {
+      Vec16<T> t = ld16(xp + cv * P);
+#pragma unroll
+      for (int k = 0; k < RX_HEAD_MAXK; ++k)
+        if (k < K) {
+#pragma unroll
+          for (int j = 0; j < P; ++j) acc[k] += Elem<T>::to_f(t.v[j]) * sw[k * C + cv * P + j];
+        }
+    }
+    if (act == RX_ACT_SIGMOID) {
+#pragma unroll
+      for (int k = 0; k < RX_HEAD_MAXK; ++k) acc[k] = 1.f / (1.f + expf(-acc[k]));
+    } else if (act == RX_ACT_SOFTMAX) {
+      float m = -INFINITY, s = 0.f;
+#pragma unroll
+      for (int k = 0; k < RX_HEAD_MAXK; ++k)
+        if (k < K) m = fmaxf(m, acc[k]);
+#pragma unroll
+      for (int k = 0; k < RX_HEAD_MAXK; ++k)
+        if (k < K) {
+          acc[k] = expf(acc[k] - m);
+          s += acc[k];
+        }
+#pragma unroll
+      for (int k = 0; k < RX_HEAD_MAXK; ++k) acc[k] = acc[k] / s;
+    }
+#pragma unroll
+    for (int k = 0; k < RX_HEAD_MAXK; ++k)
+      if (k < K) out[((size_t)n * K + k) * V + v] = acc[k];
+  }
+}
+
+extern "C" int rx_head_fwd(rx_dtype dt, const rx_act* x, const float* w, const float* b, int k, float* out_ncdhw, int act,
+                           void* stream) {
+  int rc;
+  if ((rc = check_vec_channels(x, dt, "rx_head_fwd"))) return rc;
+  if (!w || !b || !out_ncdhw) RX_FAIL(RX_EINVAL, "rx_head_fwd: null pointer");
+  if (k < 1 || k > RX_HEAD_MAXK) RX_FAIL(RX_EUNSUPPORTED, "rx_head_fwd: 1 <= K <= %d (got %d)", RX_HEAD_MAXK, k);
+  const long V = rx_act_voxels(x);
+  hipStream_t st = (hipStream_t)stream;
+  RX_DISPATCH_DTYPE(dt, T, {
+    int G = (int)((V + 255) / 256 > 4096 ? 4096 : (V + 255) / 256);
+    hipLaunchKernelGGL((head_fwd_kernel<T>), dim3(G, x->n), dim3(256), (size_t)k * x->c * sizeof(float), st, (const T*)x->ptr, x->ld,
+                       V * x->ld, w, b, k, out_ncdhw, (int)V, x->c, act);
+  });
+  RX_CHECK_LAUNCH("rx_head_fwd");
+  return RX_OK;
+}
+
+// backward: dx[v][c] = sum_k dout[k][v] w[k][c]; dw[k][c] = sum_v dout[k][v] x[v][c]; db[k] = sum_v dout[k][v]
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ x, int ldx, long sx,
+                                                       const float* __restrict__ w, int K, T* __restrict__ dx, int lddx, long sdx, int V,
+                                                       int C, int chunk_vox, float* __restrict__ partial /*[N][nch][K+1][C]*/) {
+  constexpr int P = Elem<T>::PER16;
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // sw[K][C] then red[(K+1)][VP][C]
+  float* sw = sm;
+  const int CV = C / P;
+  const int VP = 256 / CV > 0 ? 256 / CV : 1;
+  float* red = sm + K * C;
+  for (int i = threadIdx.x; i < K * C; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const int tid = threadIdx.x, n = blockIdx.y, chunk = blockIdx.x;
+  const int vl = tid / CV, cv = tid - vl * CV;
+  float aw[RX_HEAD_MAXK][P];
+  float ab[RX_HEAD_MAXK];
+#pragma unroll
+  for (int k = 0; k < RX_HEAD_MAXK; ++k) {
+    ab[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < P; ++j) aw[k][j] = 0.f;
+  }
+  const int v_begin = chunk * chunk_vox, v_end = min(V, v_begin + chunk_vox);
+  if (vl < VP) {
+    for (int v = v_begin + vl; v < v_end; v += VP) {
+      Vec16<T> xv = ld16(x + n * sx + (long)v * ldx + cv * P);
+      float d[P];
+#pragma unroll
+      for (int j = 0; j < P; ++j) d[j] = 0.f;
+#pragma unroll
+      for (int k = 0; k < RX_HEAD_MAXK; ++k)
+        if (k < K) {
+          float gk = dout[((size_t)n * K + k) * V + v];
+          ab[k] += gk;
+#pragma unroll
+          for (int j = 0; j < P; ++j) {
+            aw[k][j] += gk * Elem<T>::to_f(xv.v[j]);
+            d[j] += gk * sw[k * C + cv * P + j];
+          }
+        }
+      if (dx) {
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < P; ++j) o.v[j] = Elem<T>::from_f(d[j]);
+        st16(dx + n * sdx + (long)v * lddx + cv * P, o);
+      }
+    }
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int j = 0; j < P; ++j) red[(k * VP + vl) * C + cv * P + j] = aw[k][j];
+    // bias plane: only column cv==0 carries the sum, stored at channel 0 of plane K
+    if (cv == 0)
+      for (int k = 0; k < K; ++k) red[(K * VP + vl) * C + k] = ab[k];
+  }
+  __syncthreads();
+  float* pout = partial + (size_t)(n * gridDim.x + chunk) * (K + 1) * C;
+  for (int i = tid; i < (K + 1) * C; i += 256) {
+    int a = i / C, c = i - a * C;
+    if (a == K && c >= K) {
+      pout[i] = 0.f;
+      continue;
+    }
+    float s = 0.f;
+    for (int r = 0; r < VP; ++r) s += red[(a * VP + r) * C + c];
+    pout[i] = s;
+  }
+}
+
+extern "C" size_t rx_head_bwd_workspace(const rx_act* x, int k) {
+  if (!rx_act_ok(x)) return 0;
+  return rx_reduce_ws_bytes(x->n, rx_act_voxels(x), x->c, k + 1) + (size_t)(k + 1) * x->c * sizeof(float) + 256;
+}
+
+extern "C" int rx_head_bwd(rx_dtype dt, const float* dout_ncdhw, const rx_act* x, const float* w, int k, const rx_act* dx, float* dw,
+                           float* db, void* ws, size_t ws_bytes, void* stream) {
+  int rc;
+  if ((rc = check_vec_channels(x, dt, "rx_head_bwd(x)"))) return rc;
+  if (dx) {
+    if ((rc = check_vec_channels(dx, dt, "rx_head_bwd(dx)"))) return rc;
+    if (!same_geom(x, dx)) RX_FAIL(RX_EINVAL, "rx_head_bwd: dx geometry mismatch");
+  }
+  if (!dout_ncdhw || !w || !dw || !db || !ws) RX_FAIL(RX_EINVAL, "rx_head_bwd: null pointer");
+  if (k < 1 || k > RX_HEAD_MAXK || k > x->c) RX_FAIL(RX_EUNSUPPORTED, "rx_head_bwd: 1 <= K <= %d", RX_HEAD_MAXK);
+  const long V = rx_act_voxels(x);
+  const int N = x->n, C = x->c;
+  hipStream_t st = (hipStream_t)stream;
+  RX_DISPATCH_DTYPE(dt, T, {
+    constexpr int P = Elem<T>::PER16;
+    ReducePlan p = rx_reduce_plan(V, C, P);
+    size_t need = (size_t)N * p.nchunks * (k + 1) * C * sizeof(float) + (size_t)(k + 1) * C * sizeof(float) + 256;
+    if (ws_bytes < need) RX_FAIL(RX_EWORKSPACE, "rx_head_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
+    int CV = C / P, VP = 256 / CV;
+    float* partial = (float*)ws;
+    float* fin = partial + (size_t)N * p.nchunks * (k + 1) * C;
+    size_t lds = ((size_t)k * C + (size_t)(k + 1) * VP * C) * sizeof(float);
+    hipLaunchKernelGGL((head_bwd_kernel<T>), dim3(p.nchunks, N), dim3(256), lds, st, dout_ncdhw, (const T*)x->ptr, x->ld, V * x->ld, w, k,
+                       dx ? (T*)dx->ptr : (T*)nullptr, dx ? dx->ld : 0, dx ? V * dx->ld : 0L, (int)V, C, p.chunk_vox, partial);
+    hipLaunchKernelGGL(colreduce_finalize, dim3(((k + 1) * C + 255) / 256), dim3(256), 0, st, (const float*)partial, N, p.nchunks, k + 1,
+                       C, (double)V, 0.f, (int)FIN_SUM_OVER_N, fin);
+    (void)hipMemcpyAsync(dw, fin, (size_t)k * C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(db, fin + (size_t)k * C, (size_t)k * sizeof(float), hipMemcpyDeviceToDevice, st);
+  });
+  RX_CHECK_LAUNCH("rx_head_bwd");
+  return RX_OK;
+}
+
+// ---- stem convolution on the NCDHW fp32 image (Cin <= 4) ------------------------------------
+// thread -> (voxel, vector of P output channels); weights in LDS as [tap*Cin][Cout]
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, int Cin, int Z, int Y, int X, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, T* __restrict__ out, int ldo, long so, int Co, int kz,
+                                                       int ky, int kx) {
+  constexpr int P = Elem<T>::PER16;
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [Cin*T][Co]
+  const int TT = kz * ky * kx;
+  for (int i = threadIdx.x; i < Co * Cin * TT; i += 256) {
+    int co = i / (Cin * TT), r = i - co * (Cin * TT);  // r = ci*TT + t  (torch layout (Co,Ci,T))
+    sw[r * Co + co] = w[i];
+  }
+  __syncthreads();
+  const int n = blockIdx.y;
+  const int CV = Co / P;
+  const long V = (long)Z * Y * X;
+  const long total = V * CV;
+  const int pz = (kz - 1) / 2, py = (ky - 1) / 2, px = (kx - 1) / 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int cv = (int)(i % CV);
+    long v = i / CV;
+    int xx = (int)(v % X), yy = (int)((v / X) % Y), zz = (int)(v / ((long)X * Y));
+    float acc[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) acc[j] = bias ? bias[cv * P + j] : 0.f;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* xc = x + ((size_t)n * Cin + ci) * V;
+      for (int a = 0; a < kz; ++a) {
+        int z2 = zz + a - pz;
+        if ((unsigned)z2 >= (unsigned)Z) continue;
+        for (int b = 0; b < ky; ++b) {
+          int y2 = yy + b - py;
+          if ((unsigned)y2 >= (unsigned)Y) continue;
+          for (int c = 0; c < kx; ++c) {
+            int x2 = xx + c - px;
+            if ((unsigned)x2 >= (unsigned)X) continue;
+            float xv = xc[((long)z2 * Y + y2) * X + x2];
+            const float* wr = sw + ((ci * TT) + (a * ky + b) * kx + c) * Co + cv * P;
+#pragma unroll
+            for (int j = 0; j < P; ++j) acc[j] += xv * wr[j];
+          }
+        }
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < P; ++j) o.v[j] = Elem<T>::from_f(acc[j]);
+    st16(out + n * so + v * ldo + cv * P, o);
+  }
+}
+
+static int check_kernel13(const int32_t k[3], const char* who) {
+  for (int i = 0; i < 3; ++i)
+    if (k[i] != 1 && k[i] != 3) RX_FAIL(RX_EUNSUPPORTED, "%s: kernel sizes must be 1 or 3", who);
+  return RX_OK;
+}
+
+extern "C" int rx_stem_conv_fwd(rx_dtype dt, const float* x_ncdhw, int n, int cin, int z, int y, int x, const float* w,
+                                const float* bias, const rx_act* out, const int32_t kernel[3], void* stream) {
+  int rc;
+  if ((rc = check_vec_channels(out, dt, "rx_stem_conv_fwd(out)"))) return rc;
+  if ((rc = check_kernel13(kernel, "rx_stem_conv_fwd"))) return rc;
+  if (!x_ncdhw || !w || cin < 1 || cin > 4) RX_FAIL(RX_EUNSUPPORTED, "rx_stem_conv_fwd: 1 <= Cin <= 4");
+  if (out->n != n || out->z != z || out->y != y || out->x != x) RX_FAIL(RX_EINVAL, "rx_stem_conv_fwd: geometry mismatch");
+  hipStream_t st = (hipStream_t)stream;
+  const int TT = kernel[0] * kernel[1] * kernel[2];
+  RX_DISPATCH_DTYPE(dt, T, {
+    constexpr int P = Elem<T>::PER16;
+    long total = rx_act_voxels(out) * (out->c / P);
+    int G = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL((stem_fwd_kernel<T>), dim3(G, n), dim3(256), (size_t)out->c * cin * TT * sizeof(float), st, x_ncdhw, cin, z, y, x, w,
+                       bias, (T*)out->ptr, out->ld, rx_act_voxels(out) * out->ld, out->c, kernel[0], kernel[1], kernel[2]);
+  });
+  RX_CHECK_LAUNCH("rx_stem_conv_fwd");
+  return RX_OK;
+}
+
+// stem weight gradient: dw[co][ci][t] = sum_{n,v} dy[n][v][co] * x[n][ci][v + t - pad]
+// thread -> (voxel lane, vector of 4 output channels); 27 accumulators x 4 channels per input
+// channel (grid.z = ci); lanes of equal channel-vector are combined with xor-shuffles, waves
+// through LDS, blocks through the partial buffer.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, int Cin, int Z, int Y, int X, const T* __restrict__ dy,
+                                                         int ldy, long sy, int Co, int kz, int ky, int kx, int N, int chunk_vox,
+                                                         float* __restrict__ partial /*[nch][Cin][27][Co]*/) {
+  const int ci = blockIdx.z;
+  const int CQ = Co / 4;  // channel quads; requires CQ | 64
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cq = lane % CQ, vl = (threadIdx.x) / CQ;  // vl in [0, 256/CQ)
+  const int VPB = 256 / CQ;
+  const long V = (long)Z * Y * X;
+  const long NV = (long)N * V;
+  const int TT = kz * ky * kx;
+  const int pz = (kz - 1) / 2, py = (ky - 1) / 2, px = (kx - 1) / 2;
+  float acc[27][4];
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[t][j] = 0.f;
+  const long q_begin = (long)blockIdx.x * chunk_vox;
+  const long q_end = q_begin + chunk_vox < NV ? q_begin + chunk_vox : NV;
+  for (long q = q_begin + vl; q < q_end; q += VPB) {
+    int n = (int)(q / V);
+    long v = q - (long)n * V;
+    int xx = (int)(v % X), yy = (int)((v / X) % Y), zz = (int)(v / ((long)X * Y));
+    const T* dp = dy + n * sy + v * ldy + cq * 4;
+    float d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = Elem<T>::to_f(dp[j]);
+    const float* xc = x + ((size_t)n * Cin + ci) * V;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (a < kz && b < ky && c < kx) {
+            int z2 = zz + a - pz, y2 = yy + b - py, x2 = xx + c - px;
+            float xv = 0.f;
+            if ((unsigned)z2 < (unsigned)Z && (unsigned)y2 < (unsigned)Y && (unsigned)x2 < (unsigned)X)
+              xv = xc[((long)z2 * Y + y2) * X + x2];
+            const int t = (a * ky + b) * kx + c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t < 27 ? t : 0][j] += xv * d[j];
+          }
+        }
+  }
+  // combine lanes with equal cq inside the wave (lane = k*CQ + cq)
+  for (int o = CQ; o < 64; o <<= 1) {
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t][j] += __shfl_xor(acc[t][j], o, 64);
+  }
+  __shared__ float red[4][27][64];  // [wave][t][co]  (Co <= 64)
+  if (lane < CQ) {
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wave][t][cq * 4 + j] = acc[t][j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TT * Co; i += 256) {
+    int t = i / Co, co = i - t * Co;
+    float s = red[0][t][co] + red[1][t][co] + red[2][t][co] + red[3][t][co];
+    partial[(((size_t)blockIdx.x * Cin + ci) * 27 + t) * Co + co] = s;
+  }
+}
+
+__global__ void stem_wgrad_finalize(const float* __restrict__ partial, int nch, int Cin, int TT, int Co, float* __restrict__ dw) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;  // over (co, ci, t) torch layout
+  if (i >= Co * Cin * TT) return;
+  int co = i / (Cin * TT), r = i - co * (Cin * TT), ci = r / TT, t = r - ci * TT;
+  double s = 0.0;
+  for (int k = 0; k < nch; ++k) s += (double)partial[(((size_t)k * Cin + ci) * 27 + t) * Co + co];
+  dw[i] = (float)s;
+}
+
+#define RX_STEM_CHUNKS 1024
+extern "C" size_t rx_stem_conv_bwd_weight_workspace(int cin, int cout, int taps) {
+  (void)taps;
+  return (size_t)RX_STEM_CHUNKS * cin * 27 * cout * sizeof(float) + 256;
+}
+
+extern "C" int rx_stem_conv_bwd_weight(rx_dtype dt, const float* x_ncdhw, int n, int cin, int z, int y, int x, const rx_act* dy, float* dw,
+                                       const int32_t kernel[3], void* ws, size_t ws_bytes, void* stream) {
+  int rc;
+  if ((rc = check_vec_channels(dy, dt, "rx_stem_conv_bwd_weight(dy)"))) return rc;
+  if ((rc = check_kernel13(kernel, "rx_stem_conv_bwd_weight"))) return rc;
+  if (!x_ncdhw || !dw || !ws || cin < 1 || cin > 4) RX_FAIL(RX_EUNSUPPORTED, "rx_stem_conv_bwd_weight: 1 <= Cin <= 4");
+  const int Co = dy->c;
+  if (Co > 64 || Co % 4 || 64 % (Co / 4)) RX_FAIL(RX_EUNSUPPORTED, "rx_stem_conv_bwd_weight: Cout must be 4,8,16,32 or 64 (got %d)", Co);
+  if (dy->n != n || dy->z != z || dy->y != y || dy->x != x) RX_FAIL(RX_EINVAL, "rx_stem_conv_bwd_weight: geometry mismatch");
+  if (ws_bytes < rx_stem_conv_bwd_weight_workspace(cin, Co, 27)) RX_FAIL(RX_EWORKSPACE, "rx_stem_conv_bwd_weight: workspace too small");
+  const long NV = (long)n * z * y * x;
+  const int VPB = 256 / (Co / 4);
+  long chunk = (NV + RX_STEM_CHUNKS - 1) / RX_STEM_CHUNKS;
+  chunk = (chunk + VPB - 1) / VPB * VPB;
+  int nch = (int)((NV + chunk - 1) / chunk);
+  const int TT = kernel[0] * kernel[1] * kernel[2];
+  hipStream_t st = (hipStream_t)stream;
+  RX_DISPATCH_DTYPE(dt, T, {
+    hipLaunchKernelGGL((stem_wgrad_kernel<T>), dim3(nch, 1, cin), dim3(256), 0, st, x_ncdhw, cin, z, y, x, (const T*)dy->ptr, dy->ld,
+                       rx_act_voxels(dy) * dy->ld, Co, kernel[0], kernel[1], kernel[2], n, (int)chunk, (float*)ws);
+    int tot = Co * cin * TT;
+    hipLaunchKernelGGL(stem_wgrad_finalize, dim3((tot + 255) / 256), dim3(256), 0, st, (const float*)ws, nch, cin, TT, Co, dw);
+  });
+  RX_CHECK_LAUNCH("rx_stem_conv_bwd_weight");
+  return RX_OK;
+}
+
+// ---- weight packing --------------------------------------------------------------------------
+// in: w[A][B][T] fp32.  same[t'][A][B], swap[t''][B][A] where t' / t'' optionally reversed.
+// One block handles a 32(A) x 32(B) tile for all T taps through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, int A, int B, int TT, T* __restrict__ same, int flip_same,
+                                                   T* __restrict__ swp, int flip_swap) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [32 a][32*TT + 1]
+  const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+  const int rowlen = 32 * TT;
+  const int pitch = rowlen + 1;
+  for (int i = threadIdx.x; i < 32 * rowlen; i += 256) {
+    int a = i / rowlen, r = i - a * rowlen;  // r = b*TT + t
+    float v = 0.f;
+    if (a0 + a < A && b0 + r / TT < B) v = w[((size_t)(a0 + a) * B + b0) * TT + r];
+    tile[a * pitch + r] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TT * 32 * 32; i += 256) {
+    int t = i / 1024, r = i - t * 1024;
+    {
+      int a = r >> 5, b = r & 31;  // b fastest -> contiguous in same[t][a][b]
+      if (same && a0 + a < A && b0 + b < B) {
+        int to = flip_same ? TT - 1 - t : t;
+        same[((size_t)to * A + a0 + a) * B + b0 + b] = Elem<T>::from_f(tile[a * pitch + b * TT + t]);
+      }
+    }
+    {
+      int b = r >> 5, a = r & 31;  // a fastest -> contiguous in swap[t][b][a]
+      if (swp && a0 + a < A && b0 + b < B) {
+        int to = flip_swap ? TT - 1 - t : t;
+        swp[((size_t)to * B + b0 + b) * A + a0 + a] = Elem<T>::from_f(tile[a * pitch + b * TT + t]);
+      }
+    }
+  }
+}
+
+static int pack_generic(rx_dtype dt, const float* w, int A, int B, int TT, void* same, int flip_same, void* swp, int flip_swap,
+                        void* stream) {
+  if (!w || A < 1 || B < 1 || TT < 1 || TT > 27) RX_FAIL(RX_EINVAL, "rx_pack: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  RX_DISPATCH_DTYPE(dt, T, {
+    size_t lds = (size_t)32 * (32 * TT + 1) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((pack_kernel<T>), dim3((B + 31) / 32, (A + 31) / 32), dim3(256), lds, st, w, A, B, TT, (T*)same, flip_same, (T*)swp,
+                       flip_swap);
+  });
+  RX_CHECK_LAUNCH("rx_pack");
+  return RX_OK;
+}
+
+extern "C" int rx_pack_conv_weight(rx_dtype dt, const float* w, int co, int ci, int taps, void* w_fwd, void* w_bwd, void* stream) {
+  // w (Co,Ci,T): w_fwd[t][co][ci] = same; w_bwd[t][ci][co] = swap
+  return pack_generic(dt, w, co, ci, taps, w_fwd, 0, w_bwd, 0, stream);
+}
+extern "C" int rx_pack_convT_weight(rx_dtype dt, const float* w, int ci, int co, int taps, void* w_fwd, void* w_bwd, void* stream) {
+  // w (Ci,Co,T): w_fwd[t][co][ci] = swap; w_bwd[t][ci][co] = same
+  return pack_generic(dt, w, ci, co, taps, w_bwd, 0, w_fwd, 0, stream);
+}

@@ -1,0 +1,417 @@
+// rx_igemm.hip -- tap-table implicit GEMM on MFMA for every "forward-shaped" contraction of the
+// hot path:  Conv3d forward (stride 1/2), Conv3d backward-data (stride 1: one launch; stride 2:
+// one launch per output parity class), ConvTranspose3d(k=s) forward (one launch per phase) and
+// backward-data.
+//
+//   D[co][q] = sum_{tap} sum_{ci} W[tap.w][co][ci] * In[ q*is + tap.d ][ci]      (zero outside)
+//   Out[ q*os + op ][co] (+)= D[co][q] (+ bias[co])
+//
+// MFMA orientation: the WEIGHTS are the A operand (rows = output channels) and the gathered
+// ACTIVATIONS the B operand (columns = voxels), so a lane of the 32x32 accumulator holds 4 runs of
+// 4 consecutive output channels of ONE voxel -> channels-last stores of 8/16 bytes.
+// fp32 mode uses v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), bf16/f16 modes 32x32x16.
+//
+// Tiling: 256 threads = 4 waves; block tile BM voxels x BN channels; K tile = 64 bytes of input
+// channels of one tap; LDS tiles are [row][64 B] with the 16-byte chunk index XOR-swizzled by
+// (row>>2)&3 (conflict-free ds_read_b128 for the 32x32 operand fetch); register-staged double
+// buffering (global loads of tile k+1 in flight under the MFMAs of tile k).
+// Optional split-K (deep 4^3/8^3 layers: few voxels, 14 MB of weights): fp32 slabs + a
+// deterministic reduce kernel.
+#include "rx_common.h"
+
+
+struct IgemmGeom {
+  int Qz, Qy, Qx, Vq;
+  int Zi, Yi, Xi, Ci, ldi;
+  long in_ss;
+  int isz, isy, isx;
+  int Zo, Yo, Xo, Co, ldo;
+  long out_ss;
+  int osz, osy, osx, opz, opy, opx;
+  int ntaps, accumulate, ksplit, mtiles;
+  RxTap taps[27];
+};
+
+
+__device__ inline int swz(int row, int chunk) { return row * 4 + (chunk ^ ((row >> 2) & 3)); }
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
+                                                    T* __restrict__ out, float* __restrict__ slab, const IgemmGeom g) {
+  constexpr int P = Elem<T>::PER16;  // elements per 16 B
+  constexpr int KB = 4 * P;          // input channels per K tile (64 B)
+  constexpr int NB = BN / 32;        // channel blocks per wave
+  constexpr int MV = BM / 128;       // voxel blocks per wave
+  constexpr int XP = BM / 64;        // activation pieces per thread
+  constexpr int WP = (BN + 63) / 64; // weight pieces per thread
+  __shared__ u32x4 sX[2][BM * 4];
+  __shared__ u32x4 sW[2][BN * 4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mtile = blockIdx.x % g.mtiles, split = blockIdx.x / g.mtiles;
+  const int m0 = mtile * BM, n0 = blockIdx.y * BN, n = blockIdx.z;
+  const T* in_n = in + (long)n * g.in_ss;
+
+  // ---- per-thread row geometry for the activation gather (fixed for the whole K loop)
+  const int chunk = tid & 3;
+  int rz[XP], ry[XP], rx[XP];
+  bool rok[XP];
+#pragma unroll
+  for (int p = 0; p < XP; ++p) {
+    int q = m0 + (tid >> 2) + 64 * p;
+    rok[p] = q < g.Vq;
+    int qx = q % g.Qx, t = q / g.Qx;
+    int qy = t % g.Qy, qz = t / g.Qy;
+    rz[p] = qz * g.isz;
+    ry[p] = qy * g.isy;
+    rx[p] = qx * g.isx;
+  }
+  const int nkc = g.Ci / KB;
+  const int nkt_all = g.ntaps * nkc;
+  const int kt_begin = (int)((long)nkt_all * split / g.ksplit);
+  const int kt_end = (int)((long)nkt_all * (split + 1) / g.ksplit);
+
+  u32x4 xr[XP], wr[WP];
+  auto load_tile = [&](int kt) {
+    const int tap = kt / nkc, cc = kt - tap * nkc;
+    const RxTap tp = g.taps[tap];
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      int z = rz[p] + tp.dz, y = ry[p] + tp.dy, x = rx[p] + tp.dx;
+      bool ok = rok[p] && (unsigned)z < (unsigned)g.Zi && (unsigned)y < (unsigned)g.Yi && (unsigned)x < (unsigned)g.Xi;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (ok) v = *reinterpret_cast<const u32x4*>(in_n + ((long)(z * g.Yi + y) * g.Xi + x) * g.ldi + cc * KB + chunk * P);
+      xr[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < WP; ++p) {
+      int row = (tid >> 2) + 64 * p;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (row < BN) v = *reinterpret_cast<const u32x4*>(w + ((long)tp.w * g.Co + n0 + row) * g.Ci + cc * KB + chunk * P);
+      wr[p] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < XP; ++p) sX[buf][swz((tid >> 2) + 64 * p, chunk)] = xr[p];
+#pragma unroll
+    for (int p = 0; p < WP; ++p) {
+      int row = (tid >> 2) + 64 * p;
+      if (row < BN) sW[buf][swz(row, chunk)] = wr[p];
+    }
+  };
+
+  f32x16 acc[NB][MV];
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b < MV; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if (kt_begin < kt_end) {
+    load_tile(kt_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    if (kt + 1 < kt_end) load_tile(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 af[NB], bf[MV];
+#pragma unroll
+      for (int a = 0; a < NB; ++a) af[a] = sW[buf][swz(a * 32 + fr, ks * 2 + fh)];
+#pragma unroll
+      for (int b = 0; b < MV; ++b) bf[b] = sX[buf][swz(wave * (BM / 4) + b * 32 + fr, ks * 2 + fh)];
+#pragma unroll
+      for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b < MV; ++b) Mma<T>::run(acc[a][b], af[a], bf[b]);
+    }
+    if (kt + 1 < kt_end) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds voxel (lane&31) of each voxel block, channel runs 8*g4 + 4*fh + (0..3)
+#pragma unroll
+  for (int b = 0; b < MV; ++b) {
+    const int q = m0 + wave * (BM / 4) + b * 32 + fr;
+    if (q >= g.Vq) continue;
+    if (g.ksplit > 1) {
+      float* sp = slab + (((long)split * gridDim.z + n) * g.Vq + q) * g.Co + n0;
+#pragma unroll
+      for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f32x4 v = {acc[a][b][4 * g4], acc[a][b][4 * g4 + 1], acc[a][b][4 * g4 + 2], acc[a][b][4 * g4 + 3]};
+          *reinterpret_cast<f32x4*>(sp + a * 32 + 8 * g4 + 4 * fh) = v;
+        }
+      continue;
+    }
+    int qx = q % g.Qx, t = q / g.Qx;
+    int qy = t % g.Qy, qz = t / g.Qy;
+    long ov = ((long)(qz * g.osz + g.opz) * g.Yo + (qy * g.osy + g.opy)) * g.Xo + (qx * g.osx + g.opx);
+    T* op = out + (long)n * g.out_ss + ov * g.ldo + n0;
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int co = a * 32 + 8 * g4 + 4 * fh;
+        T vals[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float f = acc[a][b][4 * g4 + i];
+          if (bias) f += bias[n0 + co + i];
+          if (g.accumulate) f += Elem<T>::to_f(op[co + i]);
+          vals[i] = Elem<T>::from_f(f);
+        }
+        if (sizeof(T) == 2)
+          *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
+        else
+          *reinterpret_cast<u32x4*>(op + co) = *reinterpret_cast<u32x4*>(vals);
+      }
+  }
+}
+
+// split-K reduce: out[q*os+op][c] (+)= sum_s slab[s][n][q][c] (+ bias)
+template <typename T>
+__global__ __launch_bounds__(256) void igemm_splitk_reduce(const float* __restrict__ slab, const float* __restrict__ bias, T* __restrict__ out,
+                                                           const IgemmGeom g, int N) {
+  const int CV = g.Co / 4;
+  const long total = (long)N * g.Vq * CV;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int cv = (int)(i % CV);
+    long nq = i / CV;
+    int q = (int)(nq % g.Vq), n = (int)(nq / g.Vq);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < g.ksplit; ++k) s += *reinterpret_cast<const f32x4*>(slab + (((long)k * N + n) * g.Vq + q) * g.Co + cv * 4);
+    int qx = q % g.Qx, t = q / g.Qx;
+    int qy = t % g.Qy, qz = t / g.Qy;
+    long ov = ((long)(qz * g.osz + g.opz) * g.Yo + (qy * g.osy + g.opy)) * g.Xo + (qx * g.osx + g.opx);
+    T* op = out + (long)n * g.out_ss + ov * g.ldo + cv * 4;
+    T vals[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float f = s[j];
+      if (bias) f += bias[cv * 4 + j];
+      if (g.accumulate) f += Elem<T>::to_f(op[j]);
+      vals[j] = Elem<T>::from_f(f);
+    }
+    if (sizeof(T) == 2)
+      *reinterpret_cast<u32x2*>(op) = *reinterpret_cast<u32x2*>(vals);
+    else
+      *reinterpret_cast<u32x4*>(op) = *reinterpret_cast<u32x4*>(vals);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+
+template <typename T>
+static void igemm_dispatch_tile(int BM, int BN, dim3 grid, hipStream_t st, const void* in, const void* w, const float* bias, void* out,
+                                void* ws, const IgemmGeom& g, int N, int ks) {
+  if (BM == 256 && BN == 64)
+    hipLaunchKernelGGL((igemm_kernel<T, 256, 64>), grid, dim3(256), 0, st, (const T*)in, (const T*)w, bias, (T*)out, (float*)ws, g);
+  else if (BM == 256 && BN == 32)
+    hipLaunchKernelGGL((igemm_kernel<T, 256, 32>), grid, dim3(256), 0, st, (const T*)in, (const T*)w, bias, (T*)out, (float*)ws, g);
+  else if (BM == 128 && BN == 64)
+    hipLaunchKernelGGL((igemm_kernel<T, 128, 64>), grid, dim3(256), 0, st, (const T*)in, (const T*)w, bias, (T*)out, (float*)ws, g);
+  else
+    hipLaunchKernelGGL((igemm_kernel<T, 128, 32>), grid, dim3(256), 0, st, (const T*)in, (const T*)w, bias, (T*)out, (float*)ws, g);
+  if (ks > 1) {
+    long total = (long)N * g.Vq * (g.Co / 4);
+    int G = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL((igemm_splitk_reduce<T>), dim3(G), dim3(256), 0, st, (const float*)ws, bias, (T*)out, g, N);
+  }
+}
+
+static int igemm_launch(rx_dtype dt, const void* in, const void* w, const float* bias, void* out, IgemmGeom& g, int N, void* ws,
+                        size_t ws_bytes, hipStream_t st) {
+  const int per16 = dt == RX_F32 ? 4 : 8;
+  const int KB = 4 * per16;
+  if (g.Ci % KB) RX_FAIL(RX_EUNSUPPORTED, "igemm: input channels must be a multiple of %d (got %d)", KB, g.Ci);
+  if (g.Co % 32) RX_FAIL(RX_EUNSUPPORTED, "igemm: output channels must be a multiple of 32 (got %d)", g.Co);
+  if (g.ldi % per16 || g.ldo % 4 || ((uintptr_t)in & 15) || ((uintptr_t)out & 7) || ((uintptr_t)w & 15))
+    RX_FAIL(RX_EUNSUPPORTED, "igemm: misaligned operand (ldi=%d ldo=%d)", g.ldi, g.ldo);
+  if (g.Vq <= 0) return RX_OK;
+  const int BN = (g.Co % 64 == 0) ? 64 : 32;
+  const int BM = (g.Vq <= 128) ? 128 : 256;
+  g.mtiles = (g.Vq + BM - 1) / BM;
+  // split-K when the natural grid cannot fill the chip and K is deep
+  const long wgs = (long)g.mtiles * (g.Co / BN) * N;
+  const int nkt = g.ntaps * (g.Ci / KB);
+  int ks = 1;
+  if (wgs < 192 && nkt >= 16 && ws) {
+    ks = (int)((512 + wgs - 1) / wgs);
+    if (ks > nkt / 4) ks = nkt / 4;
+    if (ks > 32) ks = 32;
+    size_t need = (size_t)ks * N * g.Vq * g.Co * sizeof(float);
+    while (ks > 1 && need > ws_bytes) {
+      --ks;
+      need = (size_t)ks * N * g.Vq * g.Co * sizeof(float);
+    }
+    if (ks < 1) ks = 1;
+  }
+  g.ksplit = ks;
+  dim3 grid(g.mtiles * ks, g.Co / BN, N);
+  RX_DISPATCH_DTYPE(dt, T, igemm_dispatch_tile<T>(BM, BN, grid, st, in, w, bias, out, ws, g, N, ks));
+  RX_CHECK_LAUNCH("igemm");
+  return RX_OK;
+}
+
+static int check13(const int32_t k[3], const int32_t s[3], const char* who) {
+  for (int i = 0; i < 3; ++i) {
+    if (k[i] != 1 && k[i] != 3) RX_FAIL(RX_EUNSUPPORTED, "%s: kernel sizes must be 1 or 3", who);
+    if (s[i] != 1 && s[i] != 2) RX_FAIL(RX_EUNSUPPORTED, "%s: strides must be 1 or 2", who);
+  }
+  return RX_OK;
+}
+static int conv_out_dim(int in, int k, int s) { return (in + 2 * ((k - 1) / 2) - k) / s + 1; }
+
+static void geom_in(IgemmGeom& g, const rx_act* a) {
+  g.Zi = a->z, g.Yi = a->y, g.Xi = a->x, g.Ci = a->c, g.ldi = a->ld;
+  g.in_ss = rx_act_voxels(a) * (long)a->ld;
+}
+static void geom_out(IgemmGeom& g, const rx_act* a) {
+  g.Zo = a->z, g.Yo = a->y, g.Xo = a->x, g.Co = a->c, g.ldo = a->ld;
+  g.out_ss = rx_act_voxels(a) * (long)a->ld;
+}
+
+extern "C" int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, const float* bias, const rx_act* y,
+                             const int32_t kernel[3], const int32_t stride[3], void* ws, size_t wsb, void* stream) {
+  if (!rx_act_ok(x) || !rx_act_ok(y) || !w_fwd) RX_FAIL(RX_EINVAL, "rx_conv3d_fwd: bad arguments");
+  int rc = check13(kernel, stride, "rx_conv3d_fwd");
+  if (rc) return rc;
+  if (y->n != x->n || y->z != conv_out_dim(x->z, kernel[0], stride[0]) || y->y != conv_out_dim(x->y, kernel[1], stride[1]) ||
+      y->x != conv_out_dim(x->x, kernel[2], stride[2]))
+    RX_FAIL(RX_EINVAL, "rx_conv3d_fwd: output geometry mismatch");
+  IgemmGeom g;
+  memset(&g, 0, sizeof(g));
+  geom_in(g, x);
+  geom_out(g, y);
+  g.Qz = y->z, g.Qy = y->y, g.Qx = y->x, g.Vq = (int)rx_act_voxels(y);
+  g.isz = stride[0], g.isy = stride[1], g.isx = stride[2];
+  g.osz = g.osy = g.osx = 1;
+  const int pz = (kernel[0] - 1) / 2, py = (kernel[1] - 1) / 2, px = (kernel[2] - 1) / 2;
+  for (int a = 0; a < kernel[0]; ++a)
+    for (int b = 0; b < kernel[1]; ++b)
+      for (int c = 0; c < kernel[2]; ++c) {
+        RxTap& t = g.taps[g.ntaps];
+        t.dz = (int8_t)(a - pz), t.dy = (int8_t)(b - py), t.dx = (int8_t)(c - px);
+        t.w = (uint8_t)g.ntaps;
+        ++g.ntaps;
+      }
+  return igemm_launch(dt, x->ptr, w_fwd, bias, y->ptr, g, x->n, ws, wsb, (hipStream_t)stream);
+}
+
+extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx, const int32_t kernel[3],
+                                  const int32_t stride[3], int accumulate, void* ws, size_t wsb, void* stream) {
+  if (!rx_act_ok(dy) || !rx_act_ok(dx) || !w_bwd) RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_data: bad arguments");
+  int rc = check13(kernel, stride, "rx_conv3d_bwd_data");
+  if (rc) return rc;
+  if (dy->n != dx->n || dy->z != conv_out_dim(dx->z, kernel[0], stride[0]) || dy->y != conv_out_dim(dx->y, kernel[1], stride[1]) ||
+      dy->x != conv_out_dim(dx->x, kernel[2], stride[2]))
+    RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_data: geometry mismatch");
+  const int k[3] = {kernel[0], kernel[1], kernel[2]}, s[3] = {stride[0], stride[1], stride[2]};
+  const int p[3] = {(k[0] - 1) / 2, (k[1] - 1) / 2, (k[2] - 1) / 2};
+  const int din[3] = {dx->z, dx->y, dx->x};
+  // dx[s*q + r] = sum_{t : (r+p-t) % s == 0} dy[q + (r+p-t)/s] * W[t]^T      per axis
+  for (int r0 = 0; r0 < s[0]; ++r0)
+    for (int r1 = 0; r1 < s[1]; ++r1)
+      for (int r2 = 0; r2 < s[2]; ++r2) {
+        const int r[3] = {r0, r1, r2};
+        IgemmGeom g;
+        memset(&g, 0, sizeof(g));
+        geom_in(g, dy);
+        geom_out(g, dx);
+        int Q[3];
+        for (int a = 0; a < 3; ++a) Q[a] = (din[a] - r[a] + s[a] - 1) / s[a];
+        g.Qz = Q[0], g.Qy = Q[1], g.Qx = Q[2], g.Vq = Q[0] * Q[1] * Q[2];
+        g.isz = g.isy = g.isx = 1;
+        g.osz = s[0], g.osy = s[1], g.osx = s[2];
+        g.opz = r0, g.opy = r1, g.opx = r2;
+        g.accumulate = accumulate;
+        for (int a = 0; a < k[0]; ++a) {
+          if ((r0 + p[0] - a) % s[0]) continue;
+          for (int b = 0; b < k[1]; ++b) {
+            if ((r1 + p[1] - b) % s[1]) continue;
+            for (int c = 0; c < k[2]; ++c) {
+              if ((r2 + p[2] - c) % s[2]) continue;
+              RxTap& t = g.taps[g.ntaps++];
+              t.dz = (int8_t)((r0 + p[0] - a) / s[0]);
+              t.dy = (int8_t)((r1 + p[1] - b) / s[1]);
+              t.dx = (int8_t)((r2 + p[2] - c) / s[2]);
+              t.w = (uint8_t)((a * k[1] + b) * k[2] + c);
+            }
+          }
+        }
+        if (g.Vq <= 0) continue;
+        rc = igemm_launch(dt, dy->ptr, w_bwd, nullptr, dx->ptr, g, dx->n, ws, wsb, (hipStream_t)stream);
+        if (rc) return rc;
+      }
+  return RX_OK;
+}
+
+static int checkT(const int32_t s[3], const rx_act* small, const rx_act* big, const char* who) {
+  for (int i = 0; i < 3; ++i)
+    if (s[i] != 1 && s[i] != 2) RX_FAIL(RX_EUNSUPPORTED, "%s: strides must be 1 or 2", who);
+  if (small->n != big->n || big->z != small->z * s[0] || big->y != small->y * s[1] || big->x != small->x * s[2])
+    RX_FAIL(RX_EINVAL, "%s: geometry mismatch", who);
+  return RX_OK;
+}
+
+extern "C" int rx_convT3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, const float* bias, const rx_act* y,
+                              const int32_t stride[3], void* ws, size_t wsb, void* stream) {
+  if (!rx_act_ok(x) || !rx_act_ok(y) || !w_fwd) RX_FAIL(RX_EINVAL, "rx_convT3d_fwd: bad arguments");
+  int rc = checkT(stride, x, y, "rx_convT3d_fwd");
+  if (rc) return rc;
+  // y[i*s + t] = sum_ci x[i] W[ci][co][t] + b : one single-tap GEMM per phase t
+  for (int a = 0; a < stride[0]; ++a)
+    for (int b = 0; b < stride[1]; ++b)
+      for (int c = 0; c < stride[2]; ++c) {
+        IgemmGeom g;
+        memset(&g, 0, sizeof(g));
+        geom_in(g, x);
+        geom_out(g, y);
+        g.Qz = x->z, g.Qy = x->y, g.Qx = x->x, g.Vq = (int)rx_act_voxels(x);
+        g.isz = g.isy = g.isx = 1;
+        g.osz = stride[0], g.osy = stride[1], g.osx = stride[2];
+        g.opz = a, g.opy = b, g.opx = c;
+        g.ntaps = 1;
+        g.taps[0].dz = g.taps[0].dy = g.taps[0].dx = 0;
+        g.taps[0].w = (uint8_t)((a * stride[1] + b) * stride[2] + c);
+        rc = igemm_launch(dt, x->ptr, w_fwd, bias, y->ptr, g, x->n, ws, wsb, (hipStream_t)stream);
+        if (rc) return rc;
+      }
+  return RX_OK;
+}
+
+extern "C" int rx_convT3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx, const int32_t stride[3],
+                                   int accumulate, void* ws, size_t wsb, void* stream) {
+  if (!rx_act_ok(dy) || !rx_act_ok(dx) || !w_bwd) RX_FAIL(RX_EINVAL, "rx_convT3d_bwd_data: bad arguments");
+  int rc = checkT(stride, dx, dy, "rx_convT3d_bwd_data");
+  if (rc) return rc;
+  // dx[i] = sum_t dy[i*s + t] W[t]^T
+  IgemmGeom g;
+  memset(&g, 0, sizeof(g));
+  geom_in(g, dy);
+  geom_out(g, dx);
+  g.Qz = dx->z, g.Qy = dx->y, g.Qx = dx->x, g.Vq = (int)rx_act_voxels(dx);
+  g.isz = stride[0], g.isy = stride[1], g.isx = stride[2];
+  g.osz = g.osy = g.osx = 1;
+  g.accumulate = accumulate;
+  for (int a = 0; a < stride[0]; ++a)
+    for (int b = 0; b < stride[1]; ++b)
+      for (int c = 0; c < stride[2]; ++c) {
+        RxTap& t = g.taps[g.ntaps];
+        t.dz = (int8_t)a, t.dy = (int8_t)b, t.dx = (int8_t)c;
+        t.w = (uint8_t)g.ntaps;
+        ++g.ntaps;
+      }
+  return igemm_launch(dt, dy->ptr, w_bwd, nullptr, dx->ptr, g, dx->n, ws, wsb, (hipStream_t)stream);
+}
+
+extern "C" size_t rx_conv_workspace_hint(void) { return (size_t)96 << 20; }

@@ -1,0 +1,327 @@
+// rx_wgrad.hip -- weight gradients of Conv3d / ConvTranspose3d on MFMA.
+//
+//   dW[tap][r][c] = sum_q  G[q][r] * X[ q*is + tap.d ][c]          (X zero outside its volume)
+//
+// Conv3d:           G = dy (rows r = Cout), X = x  (cols c = Cin), is = stride, d = t - pad
+// ConvTranspose3d:  G = x  (rows r = Cin),  X = dy (cols c = Cout), is = stride, d = t
+// -> in both cases the result is torch's own parameter layout [r][c][T] after the reduce kernel.
+//
+// The contraction index is the VOXEL, which is the slow axis of both channels-last operands, so
+// both MFMA operands need a transposed fetch.  Tiles are staged in LDS as [32-channel panel][voxel]
+// [32 ch] rows (64 B for 16-bit types) and 16-bit operands are fetched with ds_read_b64_tr_b16
+// (4 voxels x 16 channels per 16-lane group, conflict-free on 64-byte rows); fp32 operands use
+// plain ds_read_b32 (the 32x32x2 f32 MFMA takes one value per lane).
+//
+// Work split: grid = (R/BR * C/BC, taps, ksplit).  Inside a block the 4 waves take different
+// k-steps of every 64-voxel tile and each computes the whole BR x BC tile; their accumulators are
+// combined through LDS, written as an fp32 slab [split][tap][R][C], and a second kernel sums the
+// slabs in a fixed order (deterministic, no float atomics) and transposes to [R][C][T].
+#include "rx_common.h"
+
+
+struct WgradGeom {
+  int Qz, Qy, Qx, Vq, NQ;
+  int R, ldg;
+  long g_ss;
+  int Zx, Yx, Xx, Cc, ldx;
+  long x_ss;
+  int isz, isy, isx;
+  int ntaps, ksplit, q_per_split, tiles_c;
+  RxTap taps[27];
+};
+
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// operand fetch: `panel` points at a [64 voxels][32 ch] LDS panel; returns the 32x32x(16|8) fragment
+// of k-step `ks` (16 voxels for 16-bit types, 8 voxels for fp32)
+template <typename T>
+__device__ inline u32x4 fetch_frag(const T* panel, int ks, int lane) {
+  if constexpr (sizeof(T) == 2) {
+    const int g16 = lane >> 4, half = g16 & 1, h = g16 >> 1, l15 = lane & 15, q4 = l15 >> 2, p4 = l15 & 3;
+    const T* a0 = panel + (ks * 16 + 8 * h + q4) * 32 + 16 * half + 4 * p4;
+    s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+    s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * 32));
+    u32x2 lo = __builtin_bit_cast(u32x2, t0), hi = __builtin_bit_cast(u32x2, t1);
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  } else {
+    const int i = lane & 31, h = lane >> 5;
+    const T* a0 = panel + (ks * 8 + 4 * h) * 32 + i;
+    f32x4 v = {a0[0], a0[32], a0[64], a0[96]};
+    return __builtin_bit_cast(u32x4, v);
+  }
+}
+
+template <typename T, int BR, int BC>
+__global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ gt, const T* __restrict__ xt, float* __restrict__ slab,
+                                                    const WgradGeom g) {
+  constexpr int P = Elem<T>::PER16;
+  constexpr int NR = BR / 32, NC = BC / 32;
+  constexpr int GV = 64 * BR / P / 256;  // G vectors per thread per tile
+  constexpr int XV = 64 * BC / P / 256;
+  constexpr int KSTEPS = sizeof(T) == 2 ? 4 : 8;  // k-steps per 64-voxel tile
+  constexpr int TILE_ELEMS = 64 * (BR + BC);      // elements of T per buffer
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* sbuf = reinterpret_cast<T*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile_r = blockIdx.x / g.tiles_c, tile_c = blockIdx.x - tile_r * g.tiles_c;
+  const int r0 = tile_r * BR, c0 = tile_c * BC;
+  const RxTap tp = g.taps[blockIdx.y];
+  const int q_begin = blockIdx.z * g.q_per_split;
+  const int q_end = min(g.NQ, q_begin + g.q_per_split);
+
+  u32x4 gr[GV], xr[XV];
+  auto load_tile = [&](int q0) {
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int i = tid + 256 * j, vox = i / (BR / P), cv = i - vox * (BR / P);
+      const int q = q0 + vox;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (q < q_end) {
+        const int n = q / g.Vq, vq = q - n * g.Vq;
+        v = *reinterpret_cast<const u32x4*>(gt + n * g.g_ss + (long)vq * g.ldg + r0 + cv * P);
+      }
+      gr[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int i = tid + 256 * j, vox = i / (BC / P), cv = i - vox * (BC / P);
+      const int q = q0 + vox;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (q < q_end) {
+        const int n = q / g.Vq, vq = q - n * g.Vq;
+        const int qx = vq % g.Qx, t = vq / g.Qx;
+        const int qy = t % g.Qy, qz = t / g.Qy;
+        const int z = qz * g.isz + tp.dz, y = qy * g.isy + tp.dy, x = qx * g.isx + tp.dx;
+        if ((unsigned)z < (unsigned)g.Zx && (unsigned)y < (unsigned)g.Yx && (unsigned)x < (unsigned)g.Xx)
+          v = *reinterpret_cast<const u32x4*>(xt + n * g.x_ss + ((long)(z * g.Yx + y) * g.Xx + x) * g.ldx + c0 + cv * P);
+      }
+      xr[j] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    T* base = sbuf + buf * TILE_ELEMS;
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int i = tid + 256 * j, vox = i / (BR / P), cv = i - vox * (BR / P);
+      const int c = cv * P;
+      *reinterpret_cast<u32x4*>(base + ((c >> 5) * 64 + vox) * 32 + (c & 31)) = gr[j];
+    }
+    T* xb = base + 64 * BR;
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int i = tid + 256 * j, vox = i / (BC / P), cv = i - vox * (BC / P);
+      const int c = cv * P;
+      *reinterpret_cast<u32x4*>(xb + ((c >> 5) * 64 + vox) * 32 + (c & 31)) = xr[j];
+    }
+  };
+
+  f32x16 acc[NR][NC];
+#pragma unroll
+  for (int a = 0; a < NR; ++a)
+#pragma unroll
+    for (int b = 0; b < NC; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if (q_begin < q_end) {
+    load_tile(q_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  int it = 0;
+  for (int q0 = q_begin; q0 < q_end; q0 += 64, ++it) {
+    const int buf = it & 1;
+    if (q0 + 64 < q_end) load_tile(q0 + 64);
+    const T* base = sbuf + buf * TILE_ELEMS;
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS / 4; ++kk) {
+      const int ks = wave + 4 * kk;
+      u32x4 af[NR], bf[NC];
+#pragma unroll
+      for (int a = 0; a < NR; ++a) af[a] = fetch_frag<T>(base + a * 64 * 32, ks, lane);
+#pragma unroll
+      for (int b = 0; b < NC; ++b) bf[b] = fetch_frag<T>(base + 64 * BR + b * 64 * 32, ks, lane);
+#pragma unroll
+      for (int a = 0; a < NR; ++a)
+#pragma unroll
+        for (int b = 0; b < NC; ++b) Mma<T>::run(acc[a][b], af[a], bf[b]);
+    }
+    if (q0 + 64 < q_end) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- combine the 4 waves through LDS (aliases the staging buffers; all reads of them are done)
+  float* red = reinterpret_cast<float*>(smem);  // [wave][a][b][row 32][col 32]
+  const int col = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < NR; ++a)
+#pragma unroll
+    for (int b = 0; b < NC; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+        red[(((wave * NR + a) * NC + b) * 32 + row) * 32 + col] = acc[a][b][r];
+      }
+  __syncthreads();
+  float* out = slab + ((long)blockIdx.z * g.ntaps + blockIdx.y) * g.R * g.Cc;
+  for (int i = tid; i < NR * NC * 1024; i += 256) {
+    const int blk = i >> 10, rc = i & 1023, row = rc >> 5, cc = rc & 31;
+    const int a = blk / NC, b = blk - a * NC;
+    float s = red[i] + red[i + NR * NC * 1024] + red[i + 2 * NR * NC * 1024] + red[i + 3 * NR * NC * 1024];
+    out[(long)(r0 + a * 32 + row) * g.Cc + c0 + b * 32 + cc] = s;
+  }
+}
+
+// dw[r][c][t] = sum_s slab[s][t][r][c]
+__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ slab, int S, int T_, int R, int C, float* __restrict__ dw) {
+  const long RC = (long)R * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < RC; i += (long)gridDim.x * 256) {
+    for (int t = 0; t < T_; ++t) {
+      float s = 0.f;
+      for (int k = 0; k < S; ++k) s += slab[((long)k * T_ + t) * RC + i];
+      dw[i * T_ + t] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int plan_split(const WgradGeom& g, int BR, int BC, size_t ws_bytes, int* ksplit, int* qps) {
+  const long tiles = (long)(g.R / BR) * (g.Cc / BC) * g.ntaps;
+  const long ktiles = ((long)g.NQ + 63) / 64;
+  long S = (1024 + tiles - 1) / tiles;
+  if (S > ktiles / 4) S = ktiles / 4;
+  if (S < 1) S = 1;
+  const size_t slab1 = (size_t)g.ntaps * g.R * g.Cc * sizeof(float);
+  while (S > 1 && S * slab1 > ws_bytes) --S;
+  if (slab1 > ws_bytes) return RX_EWORKSPACE;
+  long per = (ktiles + S - 1) / S;
+  S = (ktiles + per - 1) / per;
+  *ksplit = (int)S;
+  *qps = (int)(per * 64);
+  return RX_OK;
+}
+
+static size_t wgrad_ws_bytes(int R, int C, int taps, long NQ) {
+  const size_t slab1 = (size_t)taps * R * C * sizeof(float);
+  const long tiles = (long)((R + 63) / 64) * ((C + 63) / 64) * taps;
+  long S = (1024 + tiles - 1) / tiles;
+  long ktiles = (NQ + 63) / 64;
+  if (S > ktiles / 4) S = ktiles / 4;
+  if (S < 1) S = 1;
+  // BR/BC may fall back to 32 (4x the tiles) -> S only shrinks; this bound is safe
+  if (R % 64 || C % 64) {
+    const long t32 = (long)(R / 32) * (C / 32) * taps;
+    long S2 = (1024 + t32 - 1) / t32;
+    if (S2 > S) S = S2;
+  }
+  return S * slab1 + 256;
+}
+
+template <typename T>
+static void wgrad_dispatch(int BR, int BC, dim3 grid, hipStream_t st, const void* gt, const void* xt, float* slab, const WgradGeom& g) {
+  const size_t lds = 65536;
+#define RX_WG(BR_, BC_)                                                                                                            \
+  do {                                                                                                                             \
+    static bool attr_set = false;                                                                                                  \
+    if (!attr_set) {                                                                                                               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BR_, BC_>),                                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                             \
+      attr_set = true;                                                                                                             \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((wgrad_kernel<T, BR_, BC_>), grid, dim3(256), lds, st, (const T*)gt, (const T*)xt, slab, g);                \
+  } while (0)
+  if (BR == 64 && BC == 64)
+    RX_WG(64, 64);
+  else if (BR == 64 && BC == 32)
+    RX_WG(64, 32);
+  else if (BR == 32 && BC == 64)
+    RX_WG(32, 64);
+  else
+    RX_WG(32, 32);
+#undef RX_WG
+}
+
+static int wgrad_launch(rx_dtype dt, const void* gt, const void* xt, float* dw, WgradGeom& g, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int per16 = dt == RX_F32 ? 4 : 8;
+  if (g.R % 32 || g.Cc % 32) RX_FAIL(RX_EUNSUPPORTED, "wgrad: channel counts must be multiples of 32 (R=%d C=%d)", g.R, g.Cc);
+  if (g.ldg % per16 || g.ldx % per16 || ((uintptr_t)gt & 15) || ((uintptr_t)xt & 15)) RX_FAIL(RX_EUNSUPPORTED, "wgrad: misaligned operand");
+  if (!ws || !dw) RX_FAIL(RX_EINVAL, "wgrad: null workspace / output");
+  const int BR = g.R % 64 == 0 ? 64 : 32, BC = g.Cc % 64 == 0 ? 64 : 32;
+  g.tiles_c = g.Cc / BC;
+  int rc = plan_split(g, BR, BC, ws_bytes, &g.ksplit, &g.q_per_split);
+  if (rc) RX_FAIL(rc, "wgrad: workspace too small (%zu bytes)", ws_bytes);
+  dim3 grid((g.R / BR) * (g.Cc / BC), g.ntaps, g.ksplit);
+  RX_DISPATCH_DTYPE(dt, T, wgrad_dispatch<T>(BR, BC, grid, st, gt, xt, (float*)ws, g));
+  long RC = (long)g.R * g.Cc;
+  int G = (int)((RC + 255) / 256 > 4096 ? 4096 : (RC + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce, dim3(G), dim3(256), 0, st, (const float*)ws, g.ksplit, g.ntaps, g.R, g.Cc, dw);
+  RX_CHECK_LAUNCH("wgrad");
+  return RX_OK;
+}
+
+static int conv_out_dim(int in, int k, int s) { return (in + 2 * ((k - 1) / 2) - k) / s + 1; }
+
+extern "C" size_t rx_conv3d_bwd_weight_workspace(const rx_act* x, const rx_act* dy, const int32_t kernel[3]) {
+  if (!rx_act_ok(x) || !rx_act_ok(dy)) return 0;
+  return wgrad_ws_bytes(dy->c, x->c, kernel[0] * kernel[1] * kernel[2], (long)dy->n * rx_act_voxels(dy));
+}
+
+extern "C" int rx_conv3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw, const int32_t kernel[3],
+                                    const int32_t stride[3], void* ws, size_t ws_bytes, void* stream) {
+  if (!rx_act_ok(x) || !rx_act_ok(dy)) RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_weight: bad arguments");
+  for (int i = 0; i < 3; ++i) {
+    if (kernel[i] != 1 && kernel[i] != 3) RX_FAIL(RX_EUNSUPPORTED, "rx_conv3d_bwd_weight: kernel sizes must be 1 or 3");
+    if (stride[i] != 1 && stride[i] != 2) RX_FAIL(RX_EUNSUPPORTED, "rx_conv3d_bwd_weight: strides must be 1 or 2");
+  }
+  if (dy->n != x->n || dy->z != conv_out_dim(x->z, kernel[0], stride[0]) || dy->y != conv_out_dim(x->y, kernel[1], stride[1]) ||
+      dy->x != conv_out_dim(x->x, kernel[2], stride[2]))
+    RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_weight: geometry mismatch");
+  WgradGeom g;
+  memset(&g, 0, sizeof(g));
+  g.Qz = dy->z, g.Qy = dy->y, g.Qx = dy->x, g.Vq = (int)rx_act_voxels(dy), g.NQ = dy->n * g.Vq;
+  g.R = dy->c, g.ldg = dy->ld, g.g_ss = (long)g.Vq * dy->ld;
+  g.Zx = x->z, g.Yx = x->y, g.Xx = x->x, g.Cc = x->c, g.ldx = x->ld, g.x_ss = rx_act_voxels(x) * (long)x->ld;
+  g.isz = stride[0], g.isy = stride[1], g.isx = stride[2];
+  const int pz = (kernel[0] - 1) / 2, py = (kernel[1] - 1) / 2, px = (kernel[2] - 1) / 2;
+  for (int a = 0; a < kernel[0]; ++a)
+    for (int b = 0; b < kernel[1]; ++b)
+      for (int c = 0; c < kernel[2]; ++c) {
+        RxTap& t = g.taps[g.ntaps];
+        t.dz = (int8_t)(a - pz), t.dy = (int8_t)(b - py), t.dx = (int8_t)(c - px);
+        t.w = (uint8_t)g.ntaps;
+        ++g.ntaps;
+      }
+  return wgrad_launch(dt, dy->ptr, x->ptr, dw, g, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t rx_convT3d_bwd_weight_workspace(const rx_act* x, const rx_act* dy, const int32_t stride[3]) {
+  if (!rx_act_ok(x) || !rx_act_ok(dy)) return 0;
+  return wgrad_ws_bytes(x->c, dy->c, stride[0] * stride[1] * stride[2], (long)x->n * rx_act_voxels(x));
+}
+
+extern "C" int rx_convT3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw, const int32_t stride[3], void* ws,
+                                     size_t ws_bytes, void* stream) {
+  if (!rx_act_ok(x) || !rx_act_ok(dy)) RX_FAIL(RX_EINVAL, "rx_convT3d_bwd_weight: bad arguments");
+  for (int i = 0; i < 3; ++i)
+    if (stride[i] != 1 && stride[i] != 2) RX_FAIL(RX_EUNSUPPORTED, "rx_convT3d_bwd_weight: strides must be 1 or 2");
+  if (dy->n != x->n || dy->z != x->z * stride[0] || dy->y != x->y * stride[1] || dy->x != x->x * stride[2])
+    RX_FAIL(RX_EINVAL, "rx_convT3d_bwd_weight: geometry mismatch");
+  // dW[ci][co][t] = sum_i x[i][ci] * dy[i*s + t][co]
+  WgradGeom g;
+  memset(&g, 0, sizeof(g));
+  g.Qz = x->z, g.Qy = x->y, g.Qx = x->x, g.Vq = (int)rx_act_voxels(x), g.NQ = x->n * g.Vq;
+  g.R = x->c, g.ldg = x->ld, g.g_ss = (long)g.Vq * x->ld;
+  g.Zx = dy->z, g.Yx = dy->y, g.Xx = dy->x, g.Cc = dy->c, g.ldx = dy->ld, g.x_ss = rx_act_voxels(dy) * (long)dy->ld;
+  g.isz = stride[0], g.isy = stride[1], g.isx = stride[2];
+  for (int a = 0; a < stride[0]; ++a)
+    for (int b = 0; b < stride[1]; ++b)
+      for (int c = 0; c < stride[2]; ++c) {
+        RxTap& t = g.taps[g.ntaps];
+        t.dz = (int8_t)a, t.dy = (int8_t)b, t.dx = (int8_t)c;
+        t.w = (uint8_t)g.ntaps;
+        ++g.ntaps;
+      }
+  return wgrad_launch(dt, x->ptr, dy->ptr, dw, g, ws, ws_bytes, (hipStream_t)stream);
+}

@@ -1,0 +1,104 @@
+"""ctypes binding of librxunet.so (C ABI: include/rxunet.h).  Fails loudly when the library is
+missing -- there is no fallback path."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "librxunet.so")
+
+RX_F32, RX_BF16, RX_F16 = 0, 1, 2
+RX_ACT_NONE, RX_ACT_SIGMOID, RX_ACT_SOFTMAX = 0, 1, 2
+DTYPE_CODE = {torch.float32: RX_F32, torch.bfloat16: RX_BF16, torch.float16: RX_F16}
+
+
+class RxError(RuntimeError):
+    pass
+
+
+class RxAct(ctypes.Structure):
+    """mirror of `rx_act` (include/rxunet.h)"""
+    _fields_ = [("ptr", c_void_p), ("n", c_int32), ("z", c_int32), ("y", c_int32), ("x", c_int32),
+                ("c", c_int32), ("ld", c_int32)]
+
+
+I3 = c_int32 * 3
+_P = POINTER(RxAct)
+
+_SIGNATURES = {
+    "rx_abi_version": (c_int, []),
+    "rx_last_error": (c_char_p, []),
+    "rx_device_arch_ok": (c_int, []),
+    "rx_pack_conv_weight": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rx_pack_convT_weight": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rx_conv_workspace_hint": (c_size_t, []),
+    "rx_conv3d_fwd": (c_int, [c_int, _P, c_void_p, c_void_p, _P, I3, I3, c_void_p, c_size_t, c_void_p]),
+    "rx_conv3d_bwd_data": (c_int, [c_int, _P, c_void_p, _P, I3, I3, c_int, c_void_p, c_size_t, c_void_p]),
+    "rx_conv3d_bwd_weight_workspace": (c_size_t, [_P, _P, I3]),
+    "rx_conv3d_bwd_weight": (c_int, [c_int, _P, _P, c_void_p, I3, I3, c_void_p, c_size_t, c_void_p]),
+    "rx_convT3d_fwd": (c_int, [c_int, _P, c_void_p, c_void_p, _P, I3, c_void_p, c_size_t, c_void_p]),
+    "rx_convT3d_bwd_data": (c_int, [c_int, _P, c_void_p, _P, I3, c_int, c_void_p, c_size_t, c_void_p]),
+    "rx_convT3d_bwd_weight_workspace": (c_size_t, [_P, _P, I3]),
+    "rx_convT3d_bwd_weight": (c_int, [c_int, _P, _P, c_void_p, I3, c_void_p, c_size_t, c_void_p]),
+    "rx_instnorm_stats_workspace": (c_size_t, [_P]),
+    "rx_instnorm_stats": (c_int, [c_int, _P, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rx_instnorm_act_fwd": (c_int, [c_int, _P, c_void_p, _P, _P, c_float, c_void_p]),
+    "rx_instnorm_act_bwd": (c_int, [c_int, _P, _P, c_void_p, _P, c_float, _P, _P, c_int, c_void_p, c_size_t,
+                                    c_void_p]),
+    "rx_avgpool_fwd": (c_int, [c_int, _P, _P, I3, c_void_p]),
+    "rx_avgpool_bwd": (c_int, [c_int, _P, _P, I3, c_int, c_void_p]),
+    "rx_stem_conv_fwd": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, _P, I3,
+                                 c_void_p]),
+    "rx_stem_conv_bwd_weight_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "rx_stem_conv_bwd_weight": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, _P, c_void_p, I3,
+                                        c_void_p, c_size_t, c_void_p]),
+    "rx_head_fwd": (c_int, [c_int, _P, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "rx_head_bwd_workspace": (c_size_t, [_P, c_int]),
+    "rx_head_bwd": (c_int, [c_int, c_void_p, _P, c_void_p, c_int, _P, c_void_p, c_void_p, c_void_p, c_size_t,
+                            c_void_p]),
+    "rx_channel_sum_workspace": (c_size_t, [_P]),
+    "rx_channel_sum": (c_int, [c_int, _P, c_void_p, c_void_p, c_size_t, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises RxError (never falls back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RxError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+                      "(hipcc --offload-arch=gfx950); this engine has no PyTorch/CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI drift, also loud
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().rx_last_error().decode("utf-8", "replace")
+        raise RxError(f"{what} failed with status {rc}: {msg}")
+
+
+def require_device():
+    """The compute entry points only exist for gfx950; anything else is an error, not a fallback."""
+    if not torch.cuda.is_available():
+        raise RxError("no HIP device visible: the rxunet engine runs only on an MI355X (gfx950)")
+    if not load().rx_device_arch_ok():
+        raise RxError("current HIP device is not gfx950")
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

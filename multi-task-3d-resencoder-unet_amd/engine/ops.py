@@ -1,0 +1,224 @@
+"""Thin Python wrappers over the C ABI (one function per entry point of include/rxunet.h).
+
+`Act` is the host-side handle of a channels-last activation `(n, z, y, x, c)` living in a torch
+tensor of shape `(n, z, y, x, ld)`; `Act.slice(c0, c)` addresses a channel range of the same
+buffer (how the decoder's `torch.cat((up, skip), 1)` -- decoder.py:147 -- is eliminated).
+Nothing here computes on the host or with torch ops: every function enqueues HIP kernels on
+torch's current stream.
+"""
+from ctypes import byref, c_void_p
+
+import torch
+
+from . import lib as _l
+from .lib import I3, RxAct, check, load, stream_ptr
+
+_WS = {}
+
+
+def workspace(nbytes=None, device=None):
+    """One scratch buffer per device, grown on demand (never inside a graph capture)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    need = int(nbytes or 0)
+    cur = _WS.get(device)
+    if cur is None or cur.numel() < need:
+        size = max(need, 192 << 20)
+        cur = torch.empty(size, dtype=torch.uint8, device=device)
+        _WS[device] = cur
+    return cur
+
+
+class Act:
+    __slots__ = ("t", "c0", "c")
+
+    def __init__(self, t, c0=0, c=None):
+        assert t.dim() == 5 and t.is_contiguous(), "Act wraps a contiguous (n,z,y,x,ld) tensor"
+        self.t, self.c0 = t, c0
+        self.c = t.shape[4] - c0 if c is None else c
+        assert 0 < self.c and c0 + self.c <= t.shape[4]
+
+    @staticmethod
+    def empty(n, z, y, x, c, dtype, device="cuda"):
+        return Act(torch.empty((n, z, y, x, c), dtype=dtype, device=device))
+
+    @staticmethod
+    def zeros(n, z, y, x, c, dtype, device="cuda"):
+        return Act(torch.zeros((n, z, y, x, c), dtype=dtype, device=device))
+
+    def slice(self, c0, c):
+        return Act(self.t, self.c0 + c0, c)
+
+    @property
+    def dtype(self):
+        return self.t.dtype
+
+    @property
+    def dims(self):
+        return tuple(self.t.shape[:4])
+
+    @property
+    def voxels(self):
+        s = self.t.shape
+        return s[1] * s[2] * s[3]
+
+    def desc(self):
+        s = self.t.shape
+        return RxAct(self.t.data_ptr() + self.c0 * self.t.element_size(), s[0], s[1], s[2], s[3], self.c, s[4])
+
+    def tensor(self):
+        """(n, z, y, x, c) view of the addressed channels (for tests / debugging)."""
+        return self.t[..., self.c0:self.c0 + self.c]
+
+    def to_ncdhw(self):
+        return self.tensor().permute(0, 4, 1, 2, 3).contiguous()
+
+    @staticmethod
+    def from_ncdhw(x, dtype=None):
+        return Act(x.permute(0, 2, 3, 4, 1).contiguous().to(dtype or x.dtype))
+
+
+def _code(dtype):
+    return _l.DTYPE_CODE[dtype]
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _ws_args(ws):
+    return c_void_p(ws.data_ptr()), ws.numel()
+
+
+# ---- parameter packing ------------------------------------------------------------------------
+def pack_conv_weight(w, dtype, w_fwd=None, w_bwd=None, want_fwd=True, want_bwd=True):
+    """w: (Co, Ci, kz, ky, kx) fp32 -> (w_fwd [T][Co][Ci], w_bwd [T][Ci][Co]) in `dtype`."""
+    co, ci = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+    if want_fwd and w_fwd is None:
+        w_fwd = torch.empty((taps, co, ci), dtype=dtype, device=w.device)
+    if want_bwd and w_bwd is None:
+        w_bwd = torch.empty((taps, ci, co), dtype=dtype, device=w.device)
+    check(load().rx_pack_conv_weight(_code(dtype), _ptr(w), co, ci, taps, _ptr(w_fwd if want_fwd else None),
+                                     _ptr(w_bwd if want_bwd else None), stream_ptr()), "rx_pack_conv_weight")
+    return w_fwd, w_bwd
+
+
+def pack_convT_weight(w, dtype, w_fwd=None, w_bwd=None, want_fwd=True, want_bwd=True):
+    """w: (Ci, Co, kz, ky, kx) fp32 -> (w_fwd [T][Co][Ci], w_bwd [T][Ci][Co])."""
+    ci, co = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+    if want_fwd and w_fwd is None:
+        w_fwd = torch.empty((taps, co, ci), dtype=dtype, device=w.device)
+    if want_bwd and w_bwd is None:
+        w_bwd = torch.empty((taps, ci, co), dtype=dtype, device=w.device)
+    check(load().rx_pack_convT_weight(_code(dtype), _ptr(w), ci, co, taps, _ptr(w_fwd if want_fwd else None),
+                                      _ptr(w_bwd if want_bwd else None), stream_ptr()), "rx_pack_convT_weight")
+    return w_fwd, w_bwd
+
+
+# ---- convolutions -----------------------------------------------------------------------------
+def conv3d_fwd(x, w_fwd, bias, y, kernel, stride, ws=None):
+    ws = workspace() if ws is None else ws
+    check(load().rx_conv3d_fwd(_code(x.dtype), byref(x.desc()), _ptr(w_fwd), _ptr(bias), byref(y.desc()),
+                               I3(*kernel), I3(*stride), *_ws_args(ws), stream_ptr()), "rx_conv3d_fwd")
+
+
+def conv3d_bwd_data(dy, w_bwd, dx, kernel, stride, accumulate=False, ws=None):
+    ws = workspace() if ws is None else ws
+    check(load().rx_conv3d_bwd_data(_code(dy.dtype), byref(dy.desc()), _ptr(w_bwd), byref(dx.desc()), I3(*kernel),
+                                    I3(*stride), int(accumulate), *_ws_args(ws), stream_ptr()), "rx_conv3d_bwd_data")
+
+
+def conv3d_bwd_weight(x, dy, dw, kernel, stride, ws=None):
+    need = load().rx_conv3d_bwd_weight_workspace(byref(x.desc()), byref(dy.desc()), I3(*kernel))
+    ws = workspace(need) if ws is None else ws
+    check(load().rx_conv3d_bwd_weight(_code(x.dtype), byref(x.desc()), byref(dy.desc()), _ptr(dw), I3(*kernel),
+                                      I3(*stride), *_ws_args(ws), stream_ptr()), "rx_conv3d_bwd_weight")
+
+
+def convT3d_fwd(x, w_fwd, bias, y, stride, ws=None):
+    ws = workspace() if ws is None else ws
+    check(load().rx_convT3d_fwd(_code(x.dtype), byref(x.desc()), _ptr(w_fwd), _ptr(bias), byref(y.desc()),
+                                I3(*stride), *_ws_args(ws), stream_ptr()), "rx_convT3d_fwd")
+
+
+def convT3d_bwd_data(dy, w_bwd, dx, stride, accumulate=False, ws=None):
+    ws = workspace() if ws is None else ws
+    check(load().rx_convT3d_bwd_data(_code(dy.dtype), byref(dy.desc()), _ptr(w_bwd), byref(dx.desc()), I3(*stride),
+                                     int(accumulate), *_ws_args(ws), stream_ptr()), "rx_convT3d_bwd_data")
+
+
+def convT3d_bwd_weight(x, dy, dw, stride, ws=None):
+    need = load().rx_convT3d_bwd_weight_workspace(byref(x.desc()), byref(dy.desc()), I3(*stride))
+    ws = workspace(need) if ws is None else ws
+    check(load().rx_convT3d_bwd_weight(_code(x.dtype), byref(x.desc()), byref(dy.desc()), _ptr(dw), I3(*stride),
+                                       *_ws_args(ws), stream_ptr()), "rx_convT3d_bwd_weight")
+
+
+# ---- InstanceNorm + LeakyReLU + residual -------------------------------------------------------
+def instnorm_stats(y, stats, eps=1e-5, ws=None):
+    ws = workspace() if ws is None else ws
+    check(load().rx_instnorm_stats(_code(y.dtype), byref(y.desc()), eps, _ptr(stats), *_ws_args(ws), stream_ptr()),
+          "rx_instnorm_stats")
+
+
+def instnorm_act_fwd(y, stats, out, slope=0.01, residual=None):
+    check(load().rx_instnorm_act_fwd(_code(y.dtype), byref(y.desc()), _ptr(stats),
+                                     byref(residual.desc()) if residual is not None else None, byref(out.desc()),
+                                     float(slope), stream_ptr()), "rx_instnorm_act_fwd")
+
+
+def instnorm_act_bwd(g, y, stats, out, dy, slope=0.01, d_residual=None, accumulate_residual=False, ws=None):
+    ws = workspace() if ws is None else ws
+    check(load().rx_instnorm_act_bwd(_code(y.dtype), byref(g.desc()), byref(y.desc()), _ptr(stats),
+                                     byref(out.desc()) if out is not None else None, float(slope), byref(dy.desc()),
+                                     byref(d_residual.desc()) if d_residual is not None else None,
+                                     int(accumulate_residual), *_ws_args(ws), stream_ptr()), "rx_instnorm_act_bwd")
+
+
+# ---- pooling ------------------------------------------------------------------------------------
+def avgpool_fwd(x, y, stride):
+    check(load().rx_avgpool_fwd(_code(x.dtype), byref(x.desc()), byref(y.desc()), I3(*stride), stream_ptr()),
+          "rx_avgpool_fwd")
+
+
+def avgpool_bwd(dy, dx, stride, accumulate=False):
+    check(load().rx_avgpool_bwd(_code(dy.dtype), byref(dy.desc()), byref(dx.desc()), I3(*stride), int(accumulate),
+                                stream_ptr()), "rx_avgpool_bwd")
+
+
+# ---- stem / head --------------------------------------------------------------------------------
+def stem_conv_fwd(x_ncdhw, w, bias, out, kernel):
+    n, cin, z, y, x = x_ncdhw.shape
+    assert x_ncdhw.dtype == torch.float32 and x_ncdhw.is_contiguous()
+    check(load().rx_stem_conv_fwd(_code(out.dtype), _ptr(x_ncdhw), n, cin, z, y, x, _ptr(w), _ptr(bias),
+                                  byref(out.desc()), I3(*kernel), stream_ptr()), "rx_stem_conv_fwd")
+
+
+def stem_conv_bwd_weight(x_ncdhw, dy, dw, kernel, ws=None):
+    n, cin, z, y, x = x_ncdhw.shape
+    need = load().rx_stem_conv_bwd_weight_workspace(cin, dy.c, 27)
+    ws = workspace(need) if ws is None else ws
+    check(load().rx_stem_conv_bwd_weight(_code(dy.dtype), _ptr(x_ncdhw), n, cin, z, y, x, byref(dy.desc()), _ptr(dw),
+                                         I3(*kernel), *_ws_args(ws), stream_ptr()), "rx_stem_conv_bwd_weight")
+
+
+def head_fwd(x, w, b, out_ncdhw, act=_l.RX_ACT_NONE):
+    k = w.shape[0]
+    check(load().rx_head_fwd(_code(x.dtype), byref(x.desc()), _ptr(w), _ptr(b), k, _ptr(out_ncdhw), int(act),
+                             stream_ptr()), "rx_head_fwd")
+
+
+def head_bwd(dout_ncdhw, x, w, dx, dw, db, ws=None):
+    k = w.shape[0]
+    need = load().rx_head_bwd_workspace(byref(x.desc()), k)
+    ws = workspace(need) if ws is None else ws
+    check(load().rx_head_bwd(_code(x.dtype), _ptr(dout_ncdhw), byref(x.desc()), _ptr(w), k,
+                             byref(dx.desc()) if dx is not None else None, _ptr(dw), _ptr(db), *_ws_args(ws),
+                             stream_ptr()), "rx_head_bwd")
+
+
+def channel_sum(x, out, ws=None):
+    ws = workspace() if ws is None else ws
+    check(load().rx_channel_sum(_code(x.dtype), byref(x.desc()), _ptr(out), *_ws_args(ws), stream_ptr()),
+          "rx_channel_sum")

@@ -1,0 +1,269 @@
+"""GPU (-m gpu): every C-ABI entry point of librxunet.so against a plain torch CPU fp64 reference
+of the torch primitive it replaces.  fp32 mode must agree to ~1e-5 (exact-fp32 MFMA / VALU);
+bf16/f16 modes are checked against the same reference evaluated on inputs rounded to the storage
+type (tolerance = a few ulps of the 8/11-bit mantissa on the output rounding, stated per test)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2, torch.float16: 2e-3}  # rel-L2 per tensor
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.engine import lib, ops as _ops
+    lib.require_device()
+    return _ops
+
+
+def rel(a, b):
+    a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+    return ((a - b).norm() / b.norm().clamp(min=1e-30)).item()
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    t = (torch.randn(shape, generator=g) * scale)
+    return t.to(dtype).double()  # value representable in the storage dtype, held in fp64
+
+
+def to_act(ops, x_ncdhw, dtype, ld=None, c0=0):
+    """NCDHW fp64 (values already representable) -> device Act, optionally inside a wider buffer."""
+    n, c, z, y, x = x_ncdhw.shape
+    ld = c if ld is None else ld
+    buf = torch.full((n, z, y, x, ld), 7.0, dtype=dtype, device="cuda")  # poison the unused channels
+    buf[..., c0:c0 + c] = x_ncdhw.permute(0, 2, 3, 4, 1).to(dtype).cuda()
+    return ops.Act(buf, c0, c)
+
+
+def out_dim(i, k, s):
+    return (i + 2 * ((k - 1) // 2) - k) // s + 1
+
+
+CONV_CASES = [
+    # (ci, co, (z,y,x), kernel, stride)
+    (32, 32, (8, 8, 8), (3, 3, 3), (1, 1, 1)),
+    (32, 64, (6, 10, 12), (3, 3, 3), (1, 1, 1)),      # ragged: voxel count not a tile multiple
+    (64, 96, (8, 8, 8), (3, 3, 3), (2, 2, 2)),        # Co % 64 != 0 -> 32-wide tile
+    (64, 64, (4, 16, 16), (3, 3, 3), (1, 2, 2)),      # anisotropic stride
+    (32, 32, (5, 8, 8), (1, 3, 3), (1, 1, 1)),        # anisotropic kernel
+    (64, 32, (8, 8, 8), (1, 1, 1), (1, 1, 1)),        # 1x1x1 projection
+    (256, 256, (4, 4, 4), (3, 3, 3), (1, 1, 1)),      # deep layer: few voxels -> split-K path
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_fwd_bwd(ops, dtype, case):
+    ci, co, dims, k, s = case
+    n = 2
+    x = rnd((n, ci, *dims), dtype, 1)
+    w = rnd((co, ci, *k), dtype, 2, scale=(ci * k[0] * k[1] * k[2]) ** -0.5)
+    b = rnd((co,), torch.float32, 3)
+    pad = [(kk - 1) // 2 for kk in k]
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv3d(xr, wr, b, stride=s, padding=pad)
+    odims = tuple(out_dim(d, kk, ss) for d, kk, ss in zip(dims, k, s))
+    assert tuple(y_ref.shape[2:]) == odims
+    gy = rnd(tuple(y_ref.shape), dtype, 4)
+    y_ref.backward(gy)
+
+    xa = to_act(ops, x, dtype, ld=ci + 32, c0=32)       # read through a channel slice (concat view)
+    w_fwd, w_bwd = ops.pack_conv_weight(w.float().cuda(), dtype)
+    ya = ops.Act.zeros(n, *odims, co, dtype)
+    ops.conv3d_fwd(xa, w_fwd, b.float().cuda(), ya, k, s)
+    assert rel(ya.to_ncdhw(), y_ref.detach()) < TOL[dtype]
+    # no bias
+    ops.conv3d_fwd(xa, w_fwd, None, ya, k, s)
+    assert rel(ya.to_ncdhw(), (y_ref.detach() - b.view(1, -1, 1, 1, 1))) < TOL[dtype]
+
+    gya = to_act(ops, gy, dtype)
+    dxa = ops.Act.zeros(n, *dims, ci, dtype)
+    ops.conv3d_bwd_data(gya, w_bwd, dxa, k, s, accumulate=False)
+    assert rel(dxa.to_ncdhw(), xr.grad) < TOL[dtype]
+    ops.conv3d_bwd_data(gya, w_bwd, dxa, k, s, accumulate=True)      # dx += ...
+    assert rel(dxa.to_ncdhw(), 2 * xr.grad) < 2 * TOL[dtype]
+
+    dw = torch.empty((co, ci, *k), dtype=torch.float32, device="cuda")
+    ops.conv3d_bwd_weight(xa, gya, dw, k, s)
+    assert rel(dw, wr.grad) < TOL[dtype]
+
+
+CONVT_CASES = [
+    (64, 32, (4, 4, 4), (2, 2, 2)),
+    (128, 64, (3, 5, 6), (2, 2, 2)),
+    (64, 64, (4, 6, 6), (1, 2, 2)),
+    (512, 256, (2, 2, 2), (2, 2, 2)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_convT3d_fwd_bwd(ops, dtype, case):
+    ci, co, dims, s = case
+    n = 2
+    x = rnd((n, ci, *dims), dtype, 5)
+    w = rnd((ci, co, *s), dtype, 6, scale=ci ** -0.5)
+    b = rnd((co,), torch.float32, 7)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv_transpose3d(xr, wr, b, stride=s)
+    gy = rnd(tuple(y_ref.shape), dtype, 8)
+    y_ref.backward(gy)
+    odims = tuple(d * ss for d, ss in zip(dims, s))
+
+    xa = to_act(ops, x, dtype)
+    w_fwd, w_bwd = ops.pack_convT_weight(w.float().cuda(), dtype)
+    # write straight into channels [0, co) of a 2*co-wide concat buffer (decoder.py:146-147)
+    cat = ops.Act(torch.full((n, *odims, 2 * co), 3.0, dtype=dtype, device="cuda"))
+    ops.convT3d_fwd(xa, w_fwd, b.float().cuda(), cat.slice(0, co), s)
+    assert rel(cat.slice(0, co).to_ncdhw(), y_ref.detach()) < TOL[dtype]
+    assert torch.all(cat.slice(co, co).tensor() == 3.0)              # the skip half is untouched
+
+    gya = to_act(ops, gy, dtype, ld=2 * co, c0=0)
+    dxa = ops.Act.zeros(n, *dims, ci, dtype)
+    ops.convT3d_bwd_data(gya, w_bwd, dxa, s)
+    assert rel(dxa.to_ncdhw(), xr.grad) < TOL[dtype]
+    dw = torch.empty((ci, co, *s), dtype=torch.float32, device="cuda")
+    ops.convT3d_bwd_weight(xa, gya, dw, s)
+    assert rel(dw, wr.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c,dims", [(32, (8, 8, 8)), (64, (5, 6, 7)), (320, (4, 4, 4)), (512, (2, 2, 2))])
+def test_instnorm_lrelu_residual(ops, dtype, c, dims):
+    n = 2
+    y = rnd((n, c, *dims), dtype, 9) * 2 + 0.5
+    r = rnd((n, c, *dims), dtype, 10)
+    g = rnd((n, c, *dims), dtype, 11)
+    ya, ra, ga = to_act(ops, y, dtype), to_act(ops, r, dtype), to_act(ops, g, dtype)
+    stats = torch.empty((n, c, 2), dtype=torch.float32, device="cuda")
+    ops.instnorm_stats(ya, stats)
+    mean_ref = y.mean(dim=(2, 3, 4))
+    var_ref = y.var(dim=(2, 3, 4), unbiased=False)
+    assert rel(stats[..., 0], mean_ref) < 1e-5
+    assert rel(stats[..., 1], (var_ref + 1e-5).rsqrt()) < 1e-5
+    for with_res, slope in [(False, 0.01), (True, 0.01), (False, 1.0)]:
+        yr = y.clone().requires_grad_(True)
+        rr = r.clone().requires_grad_(True)
+        pre = F.instance_norm(yr, eps=1e-5) + (rr if with_res else 0.0)
+        ref = F.leaky_relu(pre, slope) if slope != 1.0 else pre
+        oa = ops.Act.zeros(n, *dims, c, dtype)
+        ops.instnorm_act_fwd(ya, stats, oa, slope, ra if with_res else None)
+        assert rel(oa.to_ncdhw(), ref.detach()) < TOL[dtype]
+        # backward: feed the mask from the reference output (rounded) so both sides agree on signs
+        out_ref_act = to_act(ops, ref.detach().to(dtype).double(), dtype)
+        ref.backward(g)
+        dya = ops.Act.zeros(n, *dims, c, dtype)
+        dra = ops.Act.zeros(n, *dims, c, dtype) if with_res else None
+        ops.instnorm_act_bwd(ga, ya, stats, out_ref_act if slope != 1.0 else None, dya, slope, dra, False)
+        assert rel(dya.to_ncdhw(), yr.grad) < 3 * TOL[dtype]
+        if with_res:
+            assert rel(dra.to_ncdhw(), rr.grad) < TOL[dtype]
+            ops.instnorm_act_bwd(ga, ya, stats, out_ref_act, dya, slope, dra, True)   # accumulate
+            assert rel(dra.to_ncdhw(), 2 * rr.grad) < 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("s", [(2, 2, 2), (1, 2, 2)])
+def test_avgpool(ops, dtype, s):
+    n, c, dims = 2, 64, (4, 6, 8)
+    x = rnd((n, c, *dims), dtype, 12)
+    xr = x.clone().requires_grad_(True)
+    ref = F.avg_pool3d(xr, s, s)
+    g = rnd(tuple(ref.shape), dtype, 13)
+    ref.backward(g)
+    xa = to_act(ops, x, dtype)
+    odims = tuple(d // ss for d, ss in zip(dims, s))
+    ya = ops.Act.zeros(n, *odims, c, dtype)
+    ops.avgpool_fwd(xa, ya, s)
+    assert rel(ya.to_ncdhw(), ref.detach()) < TOL[dtype]
+    dxa = ops.Act.zeros(n, *dims, c, dtype)
+    ops.avgpool_bwd(to_act(ops, g, dtype), dxa, s)
+    assert rel(dxa.to_ncdhw(), xr.grad) < TOL[dtype]
+    ops.avgpool_bwd(to_act(ops, g, dtype), dxa, s, accumulate=True)
+    assert rel(dxa.to_ncdhw(), 2 * xr.grad) < 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,k", [(1, (3, 3, 3)), (2, (3, 3, 3)), (1, (1, 3, 3))])
+def test_stem(ops, dtype, cin, k):
+    n, co, dims = 2, 32, (6, 9, 10)
+    x = rnd((n, cin, *dims), torch.float32, 14)
+    w = rnd((co, cin, *k), torch.float32, 15, scale=0.3)
+    b = rnd((co,), torch.float32, 16)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv3d(x, wr, b, padding=[(kk - 1) // 2 for kk in k])
+    g = rnd(tuple(ref.shape), dtype, 17)
+    ref.backward(g)
+    xd = x.float().cuda().contiguous()
+    oa = ops.Act.zeros(n, *dims, co, dtype)
+    ops.stem_conv_fwd(xd, w.float().cuda(), b.float().cuda(), oa, k)
+    assert rel(oa.to_ncdhw(), ref.detach()) < TOL[dtype]
+    dw = torch.empty((co, cin, *k), dtype=torch.float32, device="cuda")
+    ops.stem_conv_bwd_weight(xd, to_act(ops, g, dtype), dw, k)
+    assert rel(dw, wr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k", [1, 3])
+def test_head(ops, dtype, k):
+    from mt3d_amd.engine import lib
+    n, c, dims = 2, 32, (6, 7, 8)
+    x = rnd((n, c, *dims), dtype, 18)
+    w = rnd((k, c), torch.float32, 19, scale=0.3)
+    b = rnd((k,), torch.float32, 20)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv3d(xr, wr.view(k, c, 1, 1, 1), br)
+    g = rnd(tuple(ref.shape), torch.float32, 21)
+    ref.backward(g)
+    xa = to_act(ops, x, dtype)
+    out = torch.empty((n, k, *dims), dtype=torch.float32, device="cuda")
+    wd, bd = w.float().cuda(), b.float().cuda()
+    ops.head_fwd(xa, wd, bd, out)
+    assert rel(out, ref.detach()) < 2e-5          # fp32 accumulate of exactly representable inputs
+    ops.head_fwd(xa, wd, bd, out, lib.RX_ACT_SIGMOID)
+    assert rel(out, torch.sigmoid(ref.detach())) < 2e-5
+    ops.head_fwd(xa, wd, bd, out, lib.RX_ACT_SOFTMAX)
+    assert rel(out, torch.softmax(ref.detach(), 1)) < 2e-5
+    dxa = ops.Act.zeros(n, *dims, c, dtype)
+    dw = torch.empty((k, c), dtype=torch.float32, device="cuda")
+    db = torch.empty((k,), dtype=torch.float32, device="cuda")
+    ops.head_bwd(g.float().cuda().contiguous(), xa, wd, dxa, dw, db)
+    assert rel(dxa.to_ncdhw(), xr.grad) < TOL[dtype]
+    assert rel(dw, wr.grad) < 2e-5
+    assert rel(db, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_channel_sum_and_pack(ops, dtype):
+    n, c, dims = 2, 64, (5, 6, 7)
+    x = rnd((n, c, *dims), dtype, 22)
+    out = torch.empty((c,), dtype=torch.float32, device="cuda")
+    ops.channel_sum(to_act(ops, x, dtype), out)
+    assert rel(out, x.sum(dim=(0, 2, 3, 4))) < 1e-5
+    w = rnd((96, 64, 3, 3, 3), dtype, 23)
+    w_fwd, w_bwd = ops.pack_conv_weight(w.float().cuda(), dtype)
+    ref = w.reshape(96, 64, 27)
+    assert torch.equal(w_fwd.double().cpu(), ref.permute(2, 0, 1))
+    assert torch.equal(w_bwd.double().cpu(), ref.permute(2, 1, 0))
+    wt = rnd((64, 32, 2, 2, 2), dtype, 24)
+    t_fwd, t_bwd = ops.pack_convT_weight(wt.float().cuda(), dtype)
+    reft = wt.reshape(64, 32, 8)
+    assert torch.equal(t_fwd.double().cpu(), reft.permute(2, 1, 0))
+    assert torch.equal(t_bwd.double().cpu(), reft.permute(2, 0, 1))
+
+
+def test_error_paths(ops):
+    from mt3d_amd.engine.lib import RxError
+    x = ops.Act.zeros(1, 4, 4, 4, 24, torch.bfloat16)      # 24 channels: not a multiple of 32
+    y = ops.Act.zeros(1, 4, 4, 4, 32, torch.bfloat16)
+    w = torch.zeros((27, 32, 24), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RxError):
+        ops.conv3d_fwd(x, w, None, y, (3, 3, 3), (1, 1, 1))
+    with pytest.raises(RxError):
+        ops.avgpool_fwd(y, y, (2, 2, 2))                    # geometry mismatch
