@@ -1,0 +1,90 @@
+"""Shared encoder container (reference: builders/encoder.py:27-170).
+
+Documented fix: the reference selects the block class with `is` comparisons
+on strings (encoder.py:74-79), which only works for interned Python literals and crashes for
+YAML-loaded values; this container compares with `==`.  The reference's quirk that
+`basic_block="ResidualBlock"` silently yields a PLAIN-conv encoder is preserved."""
+import numpy as np
+from torch import nn
+
+from .resblocks import BasicBlockD, BottleneckD, StackedResidualBlocks
+from .simple_conv_blocks import EngineOnly, StackedConvBlocks
+from .utils import get_matching_pool_op, maybe_convert_scalar_to_list
+
+
+class Encoder(EngineOnly):
+    def __init__(self, input_channels, basic_block, n_stages, features_per_stage, n_blocks_per_stage, conv_op,
+                 strides, kernel_sizes, conv_bias, norm_op, norm_op_kwargs, dropout_op, dropout_op_kwargs, nonlin,
+                 nonlin_kwargs, do_stem=True, stem_channels=None, squeeze_excitation=False,
+                 squeeze_excitation_reduction_ratio=1. / 16, stochastic_depth_p=0.0, return_skips=False,
+                 bottleneck_block=BasicBlockD, pool_type="conv", bottleneck_channels=None, n_conv_per_stage=None):
+        super().__init__()
+        if isinstance(kernel_sizes, int):
+            kernel_sizes = [kernel_sizes] * n_stages
+        if isinstance(features_per_stage, int):
+            features_per_stage = [features_per_stage] * n_stages
+        if isinstance(n_blocks_per_stage, int):
+            n_blocks_per_stage = [n_blocks_per_stage] * n_stages
+        if isinstance(strides, int):
+            strides = [strides] * n_stages
+        if bottleneck_channels is None or isinstance(bottleneck_channels, int):
+            bottleneck_channels = [bottleneck_channels] * n_stages
+        if pool_type != "conv":
+            raise NotImplementedError("pool_type != 'conv' is never selected by NetworkFromConfig "
+                                      "(build_network_from_config.py:235-259) and is not built here")
+        self.is_residual = basic_block in ("BasicBlockD", "BottleneckBlockD")
+        block = None
+        if bottleneck_block == "BottleneckBlockD":
+            block = BottleneckD
+        if basic_block == "BasicBlockD":
+            block = BasicBlockD
+        if self.is_residual and block is None:
+            # same combination that leaves `block` unbound in the reference (encoder.py:74-79)
+            raise UnboundLocalError("basic_block='BottleneckBlockD' requires bottleneck_block='BottleneckBlockD'")
+
+        if do_stem:
+            if stem_channels is None:
+                stem_channels = features_per_stage[0]
+            self.stem = StackedConvBlocks(1, conv_op, input_channels, stem_channels, kernel_sizes[0], 1, conv_bias,
+                                          norm_op, norm_op_kwargs, dropout_op, dropout_op_kwargs, nonlin, nonlin_kwargs)
+            input_channels = stem_channels
+        else:
+            self.stem = None
+
+        stages = []
+        for s in range(n_stages):
+            if self.is_residual:
+                stages.append(StackedResidualBlocks(
+                    n_blocks_per_stage[s], conv_op, input_channels, features_per_stage[s], kernel_sizes[s], strides[s],
+                    conv_bias, norm_op, norm_op_kwargs, dropout_op, dropout_op_kwargs, nonlin, nonlin_kwargs,
+                    block=block, bottleneck_channels=bottleneck_channels[s], stochastic_depth_p=stochastic_depth_p,
+                    squeeze_excitation=squeeze_excitation,
+                    squeeze_excitation_reduction_ratio=squeeze_excitation_reduction_ratio))
+            else:
+                stages.append(nn.Sequential(StackedConvBlocks(
+                    n_blocks_per_stage[s], conv_op, input_channels, features_per_stage[s], kernel_sizes[s], strides[s],
+                    conv_bias, norm_op, norm_op_kwargs, dropout_op, dropout_op_kwargs, nonlin, nonlin_kwargs)))
+            input_channels = features_per_stage[s]
+
+        self.stages = nn.Sequential(*stages)
+        self.output_channels = features_per_stage
+        self.strides = [maybe_convert_scalar_to_list(conv_op, i) for i in strides]
+        self.return_skips = return_skips
+        self.conv_op = conv_op
+        self.norm_op = norm_op
+        self.norm_op_kwargs = norm_op_kwargs
+        self.nonlin = nonlin
+        self.nonlin_kwargs = nonlin_kwargs
+        self.dropout_op = dropout_op
+        self.dropout_op_kwargs = dropout_op_kwargs
+        self.conv_bias = conv_bias
+        self.kernel_sizes = kernel_sizes
+
+    def compute_conv_feature_map_size(self, input_size):
+        out = self.stem.compute_conv_feature_map_size(input_size) if self.stem is not None else np.int64(0)
+        for s in range(len(self.stages)):
+            stage = self.stages[s]
+            stage = stage[0] if isinstance(stage, nn.Sequential) else stage
+            out += stage.compute_conv_feature_map_size(input_size)
+            input_size = [i // j for i, j in zip(input_size, self.strides[s])]
+        return out

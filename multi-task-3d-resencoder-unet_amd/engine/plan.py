@@ -1,0 +1,517 @@
+"""Static execution plan of the whole network on the HIP kernels.
+
+A `Plan` is built once per (input shape, compute dtype, needs-grad): it walks the parameter-container
+tree (`builders/*`), allocates every activation / statistics / gradient buffer up front
+(channels-last, compute dtype; sized for 288 GB of HBM -- nothing is recomputed or freed inside a
+step) and records two flat launch lists, forward and backward.  A step is then nothing but
+C-ABI calls on torch's current stream: no torch op touches an activation.
+
+Layout decisions:
+  * `torch.cat((up, skip), 1)` (decoder.py:147) never runs: the transposed conv writes channels
+    [0, C) of the concat buffer, and the encoder stage that produces the skip writes its output
+    straight into channels [C, 2C) of the FIRST task decoder's buffer (further decoders get a
+    strided copy).  Gradients mirror this.
+  * the backward list runs the decoders first (decoder 0 first, because its concat-gradient write
+    initialises the buffer the other decoders and the encoder accumulate into), then the encoder
+    in reverse.
+  * per-parameter packed copies ([tap][Co][Ci] and [tap][Ci][Co], compute dtype) are refreshed only
+    when the parameter's version counter moved.
+"""
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import lib as _l
+from . import ops
+from .ops import Act
+
+
+class UnsupportedConfig(NotImplementedError):
+    pass
+
+
+@dataclass(eq=False)
+class AT:
+    """an activation tensor of the plan and (training plans) the buffer of its gradient"""
+    act: Act
+    name: str
+    gact: Optional[Act] = None
+    written: bool = False      # plan-build-time tracking: has some backward step initialised gact?
+    needs_grad: bool = True
+
+
+@dataclass(eq=False)
+class Rec:
+    kind: str
+    a: dict = field(default_factory=dict)
+
+
+def _slope_of(nonlin):
+    if nonlin is None:
+        return 1.0
+    if isinstance(nonlin, nn.LeakyReLU):
+        return float(nonlin.negative_slope)
+    if isinstance(nonlin, nn.ReLU):
+        return 0.0
+    raise UnsupportedConfig(f"nonlinearity {type(nonlin).__name__} has no HIP kernel (LeakyReLU / ReLU only)")
+
+
+def _check_norm(norm):
+    if norm is None:
+        raise UnsupportedConfig("conv blocks without a norm layer are never produced by NetworkFromConfig")
+    if not isinstance(norm, (nn.InstanceNorm3d, nn.InstanceNorm2d)) or norm.affine or norm.track_running_stats:
+        raise UnsupportedConfig("only InstanceNorm(affine=False, track_running_stats=False) has a HIP kernel")
+    return float(norm.eps)
+
+
+class Plan:
+    def __init__(self, net, in_shape, dtype, device, needs_grad):
+        device = torch.device(device)
+        if device.type != "meta":        # a 'meta' plan only validates structure (CPU tests); it cannot run
+            _l.require_device()
+        self.net = net
+        self.dtype = dtype
+        self.device = device
+        self.needs_grad = needs_grad
+        self.in_shape = tuple(in_shape)
+        self.generation = 0
+        self.two_d = net.op_dims == 2
+        B, Cin = in_shape[0], in_shape[1]
+        spatial = tuple(in_shape[2:])
+        if self.two_d:
+            spatial = (1,) + spatial         # a 2-D net is the 3-D engine with a unit Z axis
+        self.B, self.Cin, self.spatial = B, Cin, spatial
+        self.chan_mult = 16 if dtype == torch.float32 else 32
+
+        self.params: List[nn.Parameter] = []
+        self._pidx: Dict[int, int] = {}
+        self.packs: List[dict] = []          # {param, kind, w_fwd, w_bwd, version}
+        self.enc_tape: List[Rec] = []
+        self.dec_tapes: List[List[Rec]] = []
+        self.fwd: List[Callable] = []
+        self.bwd: List[Callable] = []
+        self.dy_pool: Dict[tuple, Act] = {}
+        self._gbase: Dict[int, torch.Tensor] = {}
+        self.outputs: Dict[str, torch.Tensor] = {}
+        self.bytes_alloc = 0
+        self._x = None                        # the caller's input tensor of the current step
+        self._dlogits: Dict[str, torch.Tensor] = {}
+        self._grads: List[Optional[torch.Tensor]] = []
+        self._build()
+
+    # ------------------------------------------------------------------ helpers
+    def _k3(self, v):
+        v = list(v)
+        return [1] + v if self.two_d else v
+
+    def _new(self, dims, c, name, ld=None, needs_grad=True):
+        t = torch.empty((self.B, *dims, ld or c), dtype=self.dtype, device=self.device)
+        self.bytes_alloc += t.numel() * t.element_size()
+        return AT(Act(t, 0, c), name, needs_grad=needs_grad)
+
+    def _param(self, p):
+        if id(p) not in self._pidx:
+            self._pidx[id(p)] = len(self.params)
+            self.params.append(p)
+        return self._pidx[id(p)]
+
+    def _pack(self, p, kind):
+        if p.dim() != (4 if self.two_d else 5):
+            raise UnsupportedConfig("unexpected weight rank")
+        a, b = p.shape[0], p.shape[1]
+        taps = p[0, 0].numel()
+        co, ci = (a, b) if kind == "conv" else (b, a)
+        ent = dict(param=p, kind=kind, version=-1,
+                   w_fwd=torch.empty((taps, co, ci), dtype=self.dtype, device=self.device),
+                   w_bwd=torch.empty((taps, ci, co), dtype=self.dtype, device=self.device) if self.needs_grad else None)
+        self.bytes_alloc += 2 * ent["w_fwd"].numel() * ent["w_fwd"].element_size()
+        self.packs.append(ent)
+        return ent
+
+    def _chk_channels(self, *cs):
+        for c in cs:
+            if c % self.chan_mult:
+                raise UnsupportedConfig(f"channel count {c} is not a multiple of {self.chan_mult} "
+                                        f"(MFMA K tile of the {self.dtype} kernels)")
+
+    @staticmethod
+    def _out_dims(dims, kernel, stride):
+        return tuple((d + 2 * ((k - 1) // 2) - k) // s + 1 for d, k, s in zip(dims, kernel, stride))
+
+    # ------------------------------------------------------------------ emitters (forward tape)
+    def _emit_cdnr(self, tape, m, x: AT, out: Optional[AT] = None, residual: Optional[AT] = None,
+                   final_slope: Optional[float] = None, first_of_net=False):
+        """conv -> (dropout p=0) -> InstanceNorm -> nonlin of one ConvDropoutNormReLU container.
+        `residual`/`final_slope` fuse the block epilogue `nonlin(out + residual)` into the same
+        elementwise pass.  Returns the activated output."""
+        sp = m.spec()
+        if sp["dropout_p"] != 0.0:
+            raise UnsupportedConfig("dropout p > 0 has no HIP kernel (all reference configs use p = 0)")
+        if sp["nonlin_first"]:
+            raise UnsupportedConfig("nonlin_first=True is never selected by NetworkFromConfig")
+        eps = _check_norm(sp["norm"])
+        slope = _slope_of(sp["nonlin"]) if final_slope is None else final_slope
+        conv = sp["conv"]
+        kernel, stride = self._k3(sp["kernel"]), self._k3(sp["stride"])
+        for k in kernel:
+            if k not in (1, 3):
+                raise UnsupportedConfig(f"kernel size {k} has no HIP kernel (1 or 3 per axis)")
+        for s in stride:
+            if s not in (1, 2):
+                raise UnsupportedConfig(f"stride {s} has no HIP kernel (1 or 2 per axis)")
+        cin, cout = conv.in_channels, conv.out_channels
+        in_dims = x.act.dims[1:] if not first_of_net else self.spatial
+        odims = self._out_dims(in_dims, kernel, stride)
+        y = self._new(odims, cout, f"y:{len(tape)}")
+        stats = torch.empty((self.B, cout, 2), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = self._new(odims, cout, f"a:{len(tape)}")
+        widx = self._param(conv.weight)
+        bidx = self._param(conv.bias) if conv.bias is not None else None
+        if first_of_net:
+            if cin > 4 or any(s != 1 for s in stride):
+                raise UnsupportedConfig("the first convolution reads the NCDHW image: needs in_channels <= 4, stride 1")
+            self._chk_channels(cout)
+            tape.append(Rec("stem", dict(y=y, w=conv.weight, b=conv.bias, widx=widx, bidx=bidx, kernel=kernel)))
+        else:
+            self._chk_channels(cin, cout)
+            pk = self._pack(conv.weight, "conv")
+            tape.append(Rec("conv", dict(x=x, y=y, pk=pk, b=conv.bias, widx=widx, bidx=bidx, kernel=kernel,
+                                         stride=stride)))
+        tape.append(Rec("inact", dict(y=y, stats=stats, eps=eps, res=residual, out=out, slope=slope)))
+        return out
+
+    def _emit_block(self, tape, blk, x: AT, out: Optional[AT] = None):
+        """BasicBlockD / BottleneckD: skip path, main path, fused `nonlin(IN(conv_k(..)) + skip)`."""
+        r = x
+        for op in blk.skip_ops:
+            if isinstance(op, (nn.AvgPool3d, nn.AvgPool2d)):
+                st = self._k3(op.stride if isinstance(op.stride, (list, tuple)) else [op.stride] * (2 if self.two_d else 3))
+                odims = tuple(d // s for d, s in zip(r.act.dims[1:], st))
+                p = self._new(odims, r.act.c, f"pool:{len(tape)}")
+                tape.append(Rec("pool", dict(x=r, y=p, stride=st)))
+                r = p
+            else:
+                r = self._emit_cdnr(tape, op, r)        # 1x1 conv -> IN (no nonlin: slope 1)
+        path = blk.main_path()
+        h = x
+        for m in path[:-1]:
+            h = self._emit_cdnr(tape, m, h)
+        return self._emit_cdnr(tape, path[-1], h, out=out, residual=r, final_slope=_slope_of(blk.final_nonlin()))
+
+    # ------------------------------------------------------------------ build
+    def _build(self):
+        net = self.net
+        enc = net.shared_encoder
+        if enc.stem is None:
+            raise UnsupportedConfig("do_stem=False: the HIP path needs the stem (it converts the NCDHW image to the "
+                                    "engine's channels-last layout)")
+        tasks = list(net.task_decoders.keys())
+        n_st = len(enc.stages)
+        feats = list(enc.output_channels)
+
+        # ---- spatial size per encoder stage
+        dims = [None] * n_st
+        cur = self.spatial
+        for s in range(n_st):
+            st = self._k3(enc.strides[s])
+            kz = self._k3(enc.kernel_sizes[s] if isinstance(enc.kernel_sizes[s], (list, tuple)) else
+                          [enc.kernel_sizes[s]] * (2 if self.two_d else 3))
+            cur = self._out_dims(cur, kz, st)
+            dims[s] = cur
+
+        # ---- concat buffers of every decoder (decoder d, decoder-stage j <-> encoder stage n_st-2-j)
+        cats: List[List[AT]] = []
+        for d in range(len(tasks)):
+            row = []
+            for j in range(n_st - 1):
+                es = n_st - 2 - j
+                row.append(self._new(dims[es], 2 * feats[es], f"cat{d}.{j}", ld=2 * feats[es]))
+            cats.append(row)
+
+        def skip_home(es):
+            """where encoder stage `es` writes its output: second half of decoder 0's concat buffer"""
+            if es == n_st - 1 or not tasks:
+                return None
+            cat = cats[0][n_st - 2 - es]
+            c = feats[es]
+            return AT(cat.act.slice(c, c), f"skip{es}")
+
+        # ---- encoder
+        tape = self.enc_tape
+        x = None
+        stem_mods = list(enc.stem.convs)
+        h = self._emit_cdnr(tape, stem_mods[0], None, first_of_net=True)
+        for m in stem_mods[1:]:
+            h = self._emit_cdnr(tape, m, h)
+        skips: List[AT] = []
+        for s in range(n_st):
+            stage = enc.stages[s]
+            home = skip_home(s)
+            if enc.is_residual:
+                blocks = list(stage.blocks)
+                for bi, blk in enumerate(blocks):
+                    h = self._emit_block(tape, blk, h, out=home if bi == len(blocks) - 1 else None)
+            else:
+                mods = list(stage[0].convs)
+                for mi, m in enumerate(mods):
+                    h = self._emit_cdnr(tape, m, h, out=home if mi == len(mods) - 1 else None)
+            skips.append(h)
+
+        # ---- decoders
+        self.head_recs = []
+        for d, name in enumerate(tasks):
+            dec = net.task_decoders[name]
+            tape = []
+            self.dec_tapes.append(tape)
+            low = skips[-1]
+            for j in range(n_st - 1):
+                es = n_st - 2 - j
+                c = feats[es]
+                cat = cats[d][j]
+                up = AT(cat.act.slice(0, c), f"up{d}.{j}")
+                tconv = dec.transpconvs[j]
+                stride = self._k3(tconv.stride)
+                if list(tconv.kernel_size) != list(tconv.stride):
+                    raise UnsupportedConfig("ConvTranspose with kernel != stride")
+                self._chk_channels(tconv.in_channels, tconv.out_channels)
+                pk = self._pack(tconv.weight, "convT")
+                widx = self._param(tconv.weight)
+                bidx = self._param(tconv.bias) if tconv.bias is not None else None
+                tape.append(Rec("convT", dict(x=low, y=up, pk=pk, b=tconv.bias, widx=widx, bidx=bidx, stride=stride,
+                                              cat=cat)))
+                if d > 0:
+                    dst = AT(cat.act.slice(c, c), f"skipcopy{d}.{j}")
+                    tape.append(Rec("copy", dict(x=skips[es], y=dst, cat=cat)))
+                st_mod = dec.stages[j]
+                h = cat
+                if hasattr(st_mod, "blocks"):
+                    for blk in st_mod.blocks:
+                        h = self._emit_block(tape, blk, h)
+                else:
+                    for m in st_mod.convs:
+                        h = self._emit_cdnr(tape, m, h)
+                low = h
+            head = dec.seg_layers[-1]
+            k = head.out_channels
+            if k > 8:
+                raise UnsupportedConfig("task heads with more than 8 channels have no HIP kernel yet")
+            out = torch.empty((self.B, k, *low.act.dims[1:]), dtype=torch.float32, device=self.device)
+            self.outputs[name] = out
+            act_mod = net.task_activations[name] if name in net.task_activations else None
+            act_code = _l.RX_ACT_NONE
+            if isinstance(act_mod, nn.Sigmoid):
+                act_code = _l.RX_ACT_SIGMOID
+            elif isinstance(act_mod, nn.Softmax):
+                act_code = _l.RX_ACT_SOFTMAX
+            tape.append(Rec("head", dict(x=low, w=head.weight, b=head.bias, widx=self._param(head.weight),
+                                         bidx=self._param(head.bias), k=k, name=name, out=out, act=act_code)))
+
+        self._gen_forward()
+        if self.needs_grad:
+            self._gen_backward()
+
+    # ------------------------------------------------------------------ launch lists
+    def _gen_forward(self):
+        P = self
+        f = self.fwd
+        for tape in [self.enc_tape] + self.dec_tapes:
+            for rec in tape:
+                a = rec.a
+                if rec.kind == "stem":
+                    f.append(lambda a=a: ops.stem_conv_fwd(P._x, a["w"], a["b"], a["y"].act, a["kernel"]))
+                elif rec.kind == "conv":
+                    f.append(lambda a=a: ops.conv3d_fwd(a["x"].act, a["pk"]["w_fwd"], a["b"], a["y"].act, a["kernel"],
+                                                        a["stride"]))
+                elif rec.kind == "convT":
+                    f.append(lambda a=a: ops.convT3d_fwd(a["x"].act, a["pk"]["w_fwd"], a["b"], a["y"].act, a["stride"]))
+                elif rec.kind == "inact":
+                    def step(a=a):
+                        ops.instnorm_stats(a["y"].act, a["stats"], a["eps"])
+                        ops.instnorm_act_fwd(a["y"].act, a["stats"], a["out"].act, a["slope"],
+                                             a["res"].act if a["res"] is not None else None)
+                    f.append(step)
+                elif rec.kind == "pool":
+                    f.append(lambda a=a: ops.avgpool_fwd(a["x"].act, a["y"].act, a["stride"]))
+                elif rec.kind == "copy":
+                    f.append(lambda a=a: ops.avgpool_fwd(a["x"].act, a["y"].act, (1, 1, 1)))
+                elif rec.kind == "head":
+                    def step(a=a):
+                        w2 = a["w"].view(a["k"], -1)
+                        ops.head_fwd(a["x"].act, w2, a["b"], a["out"], a["act"] if P._apply_act else _l.RX_ACT_NONE)
+                    f.append(step)
+
+    def _dy_for(self, y: AT):
+        key = (y.act.dims, y.act.c)
+        if key not in self.dy_pool:
+            t = torch.empty((*y.act.dims, y.act.c), dtype=self.dtype, device=self.device)
+            self.bytes_alloc += t.numel() * t.element_size()
+            self.dy_pool[key] = Act(t)
+        return self.dy_pool[key]
+
+    def _gen_backward(self):
+        P = self
+        b = self.bwd
+        cat_written = {}
+
+        def mark_cat(cat):
+            cat_written[id(cat.act.t)] = True
+
+        def view_written(at):
+            return at.written or cat_written.get(id(at.act.t), False)
+
+        def new_grad(idx):
+            p = P.params[idx]
+            g = torch.empty_like(p, memory_format=torch.contiguous_format)
+            P._grads[idx] = g
+            return g
+
+        for tape in self.dec_tapes + [self.enc_tape]:
+            for rec in reversed(tape):
+                a = rec.a
+                if rec.kind == "head":
+                    x = a["x"]
+                    assert not view_written(x)
+                    gx = self._grad_buf(x)
+                    x.written = True
+
+                    def step(a=a, gx=gx):
+                        dl = P._dlogits.get(a["name"])
+                        if dl is None:      # this task did not take part in the loss
+                            gx.t.zero_()
+                            return
+                        dw, db = new_grad(a["widx"]), new_grad(a["bidx"])
+                        ops.head_bwd(dl, a["x"].act, a["w"].view(a["k"], -1), gx, dw, db)
+                    b.append(step)
+                elif rec.kind == "inact":
+                    out, y, res = a["out"], a["y"], a["res"]
+                    gout = self._grad_buf(out) if out.gact is None else out.gact
+                    if not view_written(out):
+                        raise RuntimeError(f"plan bug: gradient of {out.name} is consumed before it is produced")
+                    dy = self._dy_for(y)
+                    y.gact = dy
+                    gres, acc = None, False
+                    if res is not None:
+                        gres = self._grad_buf(res)
+                        acc = view_written(res)
+                        res.written = True
+                    b.append(lambda a=a, gout=gout, dy=dy, gres=gres, acc=acc: ops.instnorm_act_bwd(
+                        gout, a["y"].act, a["stats"], a["out"].act if a["slope"] != 1.0 else None, dy, a["slope"],
+                        gres, acc))
+                elif rec.kind in ("conv", "stem"):
+                    y = a["y"]
+                    dy = y.gact
+
+                    def wstep(a=a, dy=dy, kind=rec.kind):
+                        dw = new_grad(a["widx"])
+                        if kind == "stem":
+                            ops.stem_conv_bwd_weight(P._x, dy, dw, a["kernel"])
+                        else:
+                            ops.conv3d_bwd_weight(a["x"].act, dy, dw, a["kernel"], a["stride"])
+                        if a["bidx"] is not None:
+                            ops.channel_sum(dy, new_grad(a["bidx"]))
+                    b.append(wstep)
+                    if rec.kind == "conv":
+                        x = a["x"]
+                        gx = self._grad_buf(x)
+                        acc = view_written(x)
+                        x.written = True
+                        if x.act.c == x.act.t.shape[4] and x.act.c0 == 0:
+                            mark_cat(x)     # a full-buffer write initialises every channel view of it
+                        b.append(lambda a=a, dy=dy, gx=gx, acc=acc: ops.conv3d_bwd_data(
+                            dy, a["pk"]["w_bwd"], gx, a["kernel"], a["stride"], acc))
+                elif rec.kind == "convT":
+                    x, y = a["x"], a["y"]
+                    if not view_written(y):
+                        raise RuntimeError("plan bug: concat gradient not initialised before the transposed conv")
+                    gy = Act(a["cat"].gact.t, y.act.c0, y.act.c)
+                    gx = self._grad_buf(x)
+                    acc = view_written(x)
+                    x.written = True
+
+                    def step(a=a, gy=gy, gx=gx, acc=acc):
+                        dw = new_grad(a["widx"])
+                        ops.convT3d_bwd_weight(a["x"].act, gy, dw, a["stride"])
+                        if a["bidx"] is not None:
+                            ops.channel_sum(gy, new_grad(a["bidx"]))
+                        ops.convT3d_bwd_data(gy, a["pk"]["w_bwd"], gx, a["stride"], acc)
+                    b.append(step)
+                elif rec.kind == "pool":
+                    x, y = a["x"], a["y"]
+                    gx = self._grad_buf(x)
+                    acc = view_written(x)
+                    x.written = True
+                    assert y.gact is not None, "plan bug: pooled tensor has no gradient"
+                    b.append(lambda a=a, gy=y.gact, gx=gx, acc=acc: ops.avgpool_bwd(gy, gx, a["stride"], acc))
+                elif rec.kind == "copy":
+                    x, y = a["x"], a["y"]
+                    gy = Act(a["cat"].gact.t, y.act.c0, y.act.c)
+                    gx = self._grad_buf(x)
+                    acc = view_written(x)
+                    x.written = True
+                    b.append(lambda gy=gy, gx=gx, acc=acc: ops.avgpool_bwd(gy, gx, (1, 1, 1), acc))
+
+    def _grad_buf(self, at: AT):
+        """gradient buffer of an activation; channel views of one buffer share one gradient buffer"""
+        if at.gact is not None:
+            return at.gact
+        base = at.act.t
+        if id(base) not in self._gbase:
+            t = torch.empty_like(base)
+            self.bytes_alloc += t.numel() * t.element_size()
+            self._gbase[id(base)] = t
+        at.gact = Act(self._gbase[id(base)], at.act.c0, at.act.c)
+        return at.gact
+
+    # ------------------------------------------------------------------ run
+    def refresh_packs(self):
+        for ent in self.packs:
+            p = ent["param"]
+            if ent["version"] == p._version and ent.get("ptr") == p.data_ptr():
+                continue
+            w = p.detach()
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                w = w.float().contiguous()
+            if self.two_d:
+                w = w.unsqueeze(2)
+            if ent["kind"] == "conv":
+                ops.pack_conv_weight(w, self.dtype, ent["w_fwd"], ent["w_bwd"], True, ent["w_bwd"] is not None)
+            else:
+                ops.pack_convT_weight(w, self.dtype, ent["w_fwd"], ent["w_bwd"], True, ent["w_bwd"] is not None)
+            ent["version"] = p._version
+            ent["ptr"] = p.data_ptr()
+
+    def run_forward(self, x, apply_act):
+        if tuple(x.shape) != self.in_shape:
+            raise ValueError(f"plan built for input {self.in_shape}, got {tuple(x.shape)}")
+        x = x.detach()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        self._x = x.unsqueeze(2) if self.two_d else x
+        self._apply_act = apply_act
+        self.refresh_packs()
+        for step in self.fwd:
+            step()
+        self.generation += 1
+        outs = {}
+        for k, v in self.outputs.items():
+            outs[k] = v.squeeze(2) if self.two_d else v
+        return outs
+
+    def run_backward(self, dlogits: Dict[str, Optional[torch.Tensor]]):
+        self._dlogits = {}
+        for k, g in dlogits.items():
+            if g is None:
+                continue
+            g = g.detach()
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = g.float().contiguous()
+            self._dlogits[k] = g.unsqueeze(2) if self.two_d else g
+        self._grads = [None] * len(self.params)
+        for step in self.bwd:
+            step()
+        grads = self._grads
+        self._grads = []
+        return grads

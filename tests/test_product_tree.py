@@ -1,0 +1,90 @@
+"""CPU: the product's parameter-container tree is key-for-key / bit-for-bit the reference's
+(pinned through the golden fixtures), its engine plan has the right structure, and nothing in the
+product computes without the HIP device."""
+import pytest
+import torch
+
+import mt3d_amd  # noqa: F401
+from golden_cases import CASES
+from helpers import load_golden
+from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
+from mt3d_amd.builders.utils import get_n_blocks_per_stage, get_pool_and_conv_props
+from mt3d_amd.engine.lib import RxError
+from mt3d_amd.engine.plan import Plan, UnsupportedConfig
+import resenc_oracle as oracle
+
+
+def build_product(case):
+    c = CASES[case]
+    mgr = oracle.make_mgr(c["patch"], c["tasks"], c["in_channels"], c["batch"], c["autoconfigure"], c["model_config"])
+    torch.manual_seed(c["seed"])
+    return NetworkFromConfig(mgr), c
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_state_dict_keys_and_seeded_init_match_reference(case):
+    g = load_golden(case)
+    net, c = build_product(case)
+    assert sorted(net.state_dict().keys()) == g["state_dict_keys"]
+    assert [n for n, _ in net.named_parameters()] == g["param_names"]
+    for (n, p), ck in zip(net.named_parameters(), g["init_checksums"]):
+        assert p.numel() == int(ck[0]), n
+        assert abs(p.detach().double().sum().item() - ck[1]) <= 1e-9 * max(1.0, abs(ck[1])), n
+        assert abs(p.detach().double().norm().item() - ck[2]) <= 1e-9 * max(1.0, abs(ck[2])), n
+    topo = g["topology"]
+    assert net.num_stages == topo["num_stages"]
+    assert list(net.features_per_stage) == topo["features_per_stage"]
+
+
+@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_plan_structure_on_meta_device(case, dtype):
+    g = load_golden(case)
+    net, c = build_product(case)
+    shape = (c["batch"], c["in_channels"], *c["patch"])
+    plan = Plan(net.to("meta"), shape, dtype, "meta", needs_grad=True)
+    used = {id(p) for p in plan.params}
+    names_with_grad = {n for n, ck in zip(g["param_names"], g["grad_checksums"]) if ck[0] == 1.0}
+    names_used = {n for n, p in net.named_parameters() if id(p) in used}
+    assert names_used == names_with_grad          # unused deep-supervision heads are not engine inputs
+    assert len(plan.fwd) > 0 and len(plan.bwd) > 0
+    assert set(plan.outputs) == set(c["tasks"])
+    for name, info in c["tasks"].items():
+        assert tuple(plan.outputs[name].shape) == (c["batch"], info["channels"], *c["patch"])
+    ev = Plan(net, shape, dtype, "meta", needs_grad=False)
+    assert len(ev.bwd) == 0 and all(e["w_bwd"] is None for e in ev.packs)
+
+
+def test_planner_matches_oracle():
+    for patch in [(64, 64, 64), (128, 128, 128), (160, 160, 160), (14, 256, 256), (8, 32, 32), (256, 256)]:
+        a = get_pool_and_conv_props((1.0,) * len(patch), patch, 4, 999999)
+        b = oracle.plan_pooling(patch, 4, (1.0,) * len(patch), 999999)
+        assert (a[0], a[1], a[2]) == (b[0], b[1], b[2])
+    assert get_n_blocks_per_stage(6) == [1, 3, 4, 6, 6, 6]
+
+
+def test_no_cpu_fallback_and_loud_rejections():
+    net, c = build_product("auto16_2head")
+    with pytest.raises(RxError):
+        net(torch.zeros(2, 1, 16, 16, 16))
+    with pytest.raises(RuntimeError):
+        net.shared_encoder(torch.zeros(2, 1, 16, 16, 16))       # containers never compute
+    mgr = oracle.make_mgr((16, 16, 16), {"a": {"channels": 1}}, model_config={"squeeze_excitation": True})
+    with pytest.raises(NotImplementedError):
+        NetworkFromConfig(mgr)
+    mgr = oracle.make_mgr((16, 16, 16), {"a": {"channels": 1}}, autoconfigure=False, model_config={})
+    with pytest.raises(ValueError):
+        NetworkFromConfig(mgr)
+    mgr = oracle.make_mgr((16, 16, 16), {"a": {"channels": 1}}, model_config={"dropout_op_kwargs": {"p": 0.5}})
+    with pytest.raises(UnsupportedConfig):
+        Plan(NetworkFromConfig(mgr).to("meta"), (1, 1, 16, 16, 16), torch.float32, "meta", True)
+
+
+def test_yaml_string_blocks_do_not_crash_like_the_reference():
+    # the reference's `is` comparison breaks for YAML-loaded (non-interned) block names; fixed here
+    name = "".join(["Basic", "BlockD"])
+    mc = {"basic_encoder_block": name, "basic_decoder_block": "".join(["Conv", "Block"]), "bottleneck_block": name,
+          "features_per_stage": [32, 64], "num_stages": 2, "n_blocks_per_stage": [1, 1], "kernel_sizes": [3, 3],
+          "n_conv_per_stage_decoder": [1], "strides": [1, 2]}
+    net = NetworkFromConfig(oracle.make_mgr((16, 16, 16), {"a": {"channels": 1}}, autoconfigure=False, model_config=mc))
+    assert net.shared_encoder.is_residual
