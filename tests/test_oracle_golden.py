@@ -72,3 +72,29 @@ def test_planner_known_answers():
     assert strides[1] == (2, 2, 2) and strides[2] == (1, 2, 2)
     assert all(k == (3, 3, 3) for k in kernels)
     assert oracle.blocks_per_stage(6) == [1, 3, 4, 6, 6, 6]
+
+
+def test_fp32_gradients_are_mask_discontinuous():
+    """Why golden seeds are chosen with margin: the reference path's OWN fp32 gradients move by > 1e-3
+    against its fp64 evaluation when a single LeakyReLU mask bit differs (data seed 29), and agree to
+    ~5e-6 when none does (data seed 24).  Any implementation with a different fp32 summation order
+    (threads, oneDNN version, MFMA) sees the same effect; the 1e-3 gradient bar therefore only holds
+    on inputs whose masks have margin."""
+    from golden_cases import CASES
+    c = CASES["auto_aniso_bias"]
+    mgr = oracle.make_mgr(c["patch"], c["tasks"], c["in_channels"], c["batch"], c["autoconfigure"], c["model_config"])
+
+    def worst(data_seed):
+        res = {}
+        for dt in (torch.float32, torch.float64):
+            torch.manual_seed(c["seed"])
+            net = oracle.NetworkFromConfig(mgr).to(dt)
+            x, t = oracle.synthetic_batch(c["batch"], c["in_channels"], c["patch"], c["tasks"], data_seed)
+            out = net(x.to(dt))
+            oracle.train_loss(out, {k: v.to(dt) for k, v in t.items()}, c["tasks"]).backward()
+            res[dt] = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+        return max(rel_l2(res[torch.float32][n], res[torch.float64][n]) for n in res[torch.float32]
+                   if res[torch.float64][n].norm() > 1e-6)
+
+    assert worst(24) < 1e-4
+    assert worst(29) > 1e-3
