@@ -1,0 +1,256 @@
+#!/usr/bin/env python
+"""Headline benchmark: train patches/sec of the ResEncM 3-D residual-encoder U-Net (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One STEP = forward -> per-task loss -> backward -> (RCCL gradient all-reduce, overlapped) ->
+clip_grad_norm_(3) -> AdamW step -> zero_grad(set_to_none=True) on one synthetic batch that is already
+resident in HBM.  Workload at every N: BASELINE configs[1] = autoconfigured ResEncM,
+1-in / 1 seg head, patch 128^3, bf16, batch 2 per GPU (weak scaling: global batch 2N, configs[3] at N=8).
+Prints ONE JSON line (rank 0) with `roofline` (dominant MFMA kernel, algorithmic FLOPs / HIP-event time)
+and `cpu_baseline` (the CPU oracle = pure-PyTorch restatement of the reference, timed on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT]
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # dense, MI355X_MICROARCH.md
+DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+
+WORKLOADS = {
+    # BASELINE.json configs[1] / [3]
+    "cfg2": dict(patch=(128, 128, 128), in_channels=1, batch=2, autoconfigure=True, model_config={},
+                 tasks={"sheet": {"channels": 1, "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss",
+                                  "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}),
+    # configs[2]: + 3-channel normals regression head (second decoder)
+    "cfg3": dict(patch=(128, 128, 128), in_channels=1, batch=1, autoconfigure=True, model_config={},
+                 tasks={"sheet": {"channels": 1, "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss",
+                                  "loss_kwargs": {"alpha": 0.5, "beta": 0.5}},
+                        "normals": {"channels": 3, "activation": "none", "weight": 1, "loss_fn": "MaskedCosineLoss"}}),
+    # configs[0]: 64^3 plumbing case
+    "cfg1": dict(patch=(64, 64, 64), in_channels=1, batch=2, autoconfigure=True, model_config={},
+                 tasks={"sheet": {"channels": 1, "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss",
+                                  "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}),
+}
+
+
+def make_mgr(w):
+    from types import SimpleNamespace
+    return SimpleNamespace(tasks=w["tasks"], train_patch_size=tuple(w["patch"]), train_batch_size=w["batch"],
+                           in_channels=w["in_channels"], vram_max=16.0, autoconfigure=w["autoconfigure"],
+                           model_config=dict(w["model_config"]), verbose=False)
+
+
+def synthetic_batch(w, batch, seed, device):
+    """image rand in [0,1]; seg target (rand > 0.8); normals: unit vectors zeroed off the sheet"""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand((batch, w["in_channels"], *w["patch"]), generator=g)
+    seg = (torch.rand((batch, 1, *w["patch"]), generator=g) > 0.8).float()
+    targets = {}
+    for name, info in w["tasks"].items():
+        if info.get("loss_fn") == "MaskedCosineLoss":
+            v = torch.randn((batch, info["channels"], *w["patch"]), generator=g)
+            targets[name] = (v / v.norm(dim=1, keepdim=True).clamp(min=1e-8)) * seg
+        else:
+            targets[name] = seg
+    return x.to(device), {k: v.to(device) for k, v in targets.items()}
+
+
+def host_threads():
+    """the CPU share of this process (the GPU box gives 16 cores per GPU; os.cpu_count() reports the whole host)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def cpu_baseline_worker(workload, threads):
+    """runs in a child process: the oracle (pure-PyTorch CPU restatement of the reference path, fp32) -- one
+    warm-up step at <=32^3, then ONE timed full train step of the workload at batch 1."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import resenc_oracle as oracle
+    w = WORKLOADS[workload]
+    torch.set_num_threads(threads)
+
+    def one_step(patch, batch):
+        mgr = oracle.make_mgr(patch, w["tasks"], w["in_channels"], batch, w["autoconfigure"], w["model_config"])
+        torch.manual_seed(0)
+        net = oracle.NetworkFromConfig(mgr)
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=0.0)
+        x, t = oracle.synthetic_batch(batch, w["in_channels"], patch, w["tasks"], 1234)
+        t0 = time.perf_counter()
+        loss = oracle.train_loss(net(x), t, w["tasks"])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 3)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return time.perf_counter() - t0
+
+    one_step(tuple(min(32, p) for p in w["patch"]), 1)
+    dt = one_step(w["patch"], 1)
+    print(json.dumps(dict(value=1.0 / dt, unit="patches/s", cores=threads, kind="port",
+                          sample=f"1 full train step (fwd+loss+bwd+clip+AdamW) of {workload} at batch 1, patch "
+                                 f"{'x'.join(map(str, w['patch']))}, fp32, torch {torch.__version__} CPU, {dt:.1f} s")),
+          flush=True)
+
+
+def cpu_baseline(workload, timeout_s=300):
+    import subprocess
+    threads = host_threads()
+    print(f"[bench] timing the CPU oracle on {threads} threads (bounded: one step, <= {timeout_s} s) ...",
+          file=sys.stderr, flush=True)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload,
+                            "--cpu-threads", str(threads)], capture_output=True, text=True, timeout=timeout_s,
+                           env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads)))
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return dict(value=None, unit="patches/s", cores=threads, kind="port", sample=f"failed: {r.stderr[-300:]}")
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit="patches/s", cores=threads, kind="port",
+                    sample=f"one {workload} step at batch 1 did not finish within {timeout_s} s on {threads} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=sorted(DTYPES))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.cpu_baseline_only:
+        cpu_baseline_worker(args.workload, args.cpu_threads or host_threads())
+        return
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
+    from mt3d_amd.engine import ops
+    from mt3d_amd.engine.ddp import GradSync, broadcast_parameters
+    from mt3d_amd.training.losses.losses import LOSS_FN_MAP
+
+    w = dict(WORKLOADS[args.workload])
+    batch = args.batch or w["batch"]
+    w["batch"] = batch
+    torch.manual_seed(0)                               # random-init weights of the named architecture
+    net = NetworkFromConfig(make_mgr(w)).to(device)
+    net.compute_dtype = DTYPES[args.dtype]
+    if world > 1:
+        broadcast_parameters(net)
+    net.train()
+    loss_fns = {k: LOSS_FN_MAP[v.get("loss_fn", "BCEDiceLoss")](**v.get("loss_kwargs", {})) for k, v in w["tasks"].items()}
+    params = [p for p in net.parameters()]
+    try:
+        opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.0, fused=True)
+    except Exception:
+        opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.0)
+    x, targets = synthetic_batch(w, batch, 1234 + rank, device)
+    sync = GradSync() if world > 1 else None
+
+    def step():
+        out = net(x)
+        if sync is not None:
+            for plan in net._plans.values():
+                plan.grad_sync = sync
+        loss = 0.0
+        for name, gt in targets.items():
+            loss = loss + loss_fns[name](out[name], gt) * w["tasks"][name].get("weight", 1.0)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 3)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if rank == 0:
+        print(f"[bench] warm-up done, timing {args.steps} steps ...", file=sys.stderr, flush=True)
+    prof = None
+    if not args.no_kernel_timing and rank == 0:
+        prof = ops.LaunchProfiler()
+        ops.set_profiler(prof)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.set_profiler(None)
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    final_loss = float(loss.detach())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * batch * args.steps / dt
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        roofline, kernels = None, {}
+        if prof is not None:
+            groups = prof.collect()
+            for name, g in groups.items():
+                kernels[name] = dict(ms_per_step=g["ms"] / args.steps, avg_us_per_launch=g["ms"] * 1e3 / max(g["launches"], 1),
+                                     launches_per_step=g["launches"] / args.steps,
+                                     tflops=g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0)
+            if groups:
+                dom = max(groups, key=lambda k: groups[k]["ms"])
+                g = groups[dom]
+                ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+                roofline = dict(bound="mfma", kernel=dom, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
+                                traffic=None, avg_us_per_launch=g["ms"] * 1e3 / max(g["launches"], 1),
+                                flops_per_launch=g["flops"] / max(g["launches"], 1))
+        line = {
+            "metric": "train patches/sec (b,c,z,y,x) ResEncM 1x128^3", "value": value, "unit": "patches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: autoconfigured ResEncM (6 stages, feats 32..512, blocks 1/3/4/6/6/6), "
+                                   f"1-in, heads {list(w['tasks'])}, patch {'x'.join(map(str, w['patch']))}, "
+                                   f"batch {batch}/GPU, full train step (fwd+loss+bwd+allreduce+clip+AdamW)",
+                       "global_batch": world * batch, "parallelism": f"dp{world}"},
+            "final_loss": final_loss,
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

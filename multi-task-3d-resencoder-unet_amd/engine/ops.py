@@ -14,6 +14,44 @@ from . import lib as _l
 from .lib import I3, RxAct, check, load, stream_ptr
 
 _WS = {}
+_PROF = None      # optional launch profiler (bench.py): times the conv launches with HIP events on the
+                  # stream they are enqueued on and attributes algorithmic FLOPs to kernel instantiations
+
+
+def set_profiler(p):
+    global _PROF
+    _PROF = p
+
+
+class LaunchProfiler:
+    """HIP-event timing of the MFMA conv launches, grouped by kernel instantiation.  Used only by bench.py;
+    costs two event records per launch."""
+
+    def __init__(self):
+        self.pending = []
+        self.groups = {}
+
+    @staticmethod
+    def igemm_name(vq, co):
+        return f"igemm_kernel<{256 if vq > 128 else 128},{64 if co % 64 == 0 else 32}>"
+
+    def run(self, name, flops, launches, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.pending.append((name, flops, launches, e0, e1))
+
+    def collect(self):
+        torch.cuda.synchronize()
+        for name, flops, launches, e0, e1 in self.pending:
+            g = self.groups.setdefault(name, dict(ms=0.0, flops=0.0, calls=0, launches=0))
+            g["ms"] += e0.elapsed_time(e1)
+            g["flops"] += flops
+            g["calls"] += 1
+            g["launches"] += launches
+        self.pending = []
+        return self.groups
 
 
 def workspace(nbytes=None, device=None):
@@ -117,23 +155,49 @@ def pack_convT_weight(w, dtype, w_fwd=None, w_bwd=None, want_fwd=True, want_bwd=
 
 
 # ---- convolutions -----------------------------------------------------------------------------
+def _taps(kernel):
+    return kernel[0] * kernel[1] * kernel[2]
+
+
 def conv3d_fwd(x, w_fwd, bias, y, kernel, stride, ws=None):
     ws = workspace() if ws is None else ws
-    check(load().rx_conv3d_fwd(_code(x.dtype), byref(x.desc()), _ptr(w_fwd), _ptr(bias), byref(y.desc()),
-                               I3(*kernel), I3(*stride), *_ws_args(ws), stream_ptr()), "rx_conv3d_fwd")
+
+    def go():
+        check(load().rx_conv3d_fwd(_code(x.dtype), byref(x.desc()), _ptr(w_fwd), _ptr(bias), byref(y.desc()),
+                                   I3(*kernel), I3(*stride), *_ws_args(ws), stream_ptr()), "rx_conv3d_fwd")
+    if _PROF is None:
+        return go()
+    n = y.dims[0]
+    _PROF.run("fwd:" + LaunchProfiler.igemm_name(y.voxels, y.c), 2.0 * n * y.voxels * y.c * x.c * _taps(kernel), 1, go)
 
 
 def conv3d_bwd_data(dy, w_bwd, dx, kernel, stride, accumulate=False, ws=None):
     ws = workspace() if ws is None else ws
-    check(load().rx_conv3d_bwd_data(_code(dy.dtype), byref(dy.desc()), _ptr(w_bwd), byref(dx.desc()), I3(*kernel),
-                                    I3(*stride), int(accumulate), *_ws_args(ws), stream_ptr()), "rx_conv3d_bwd_data")
+
+    def go():
+        check(load().rx_conv3d_bwd_data(_code(dy.dtype), byref(dy.desc()), _ptr(w_bwd), byref(dx.desc()), I3(*kernel),
+                                        I3(*stride), int(accumulate), *_ws_args(ws), stream_ptr()),
+              "rx_conv3d_bwd_data")
+    if _PROF is None:
+        return go()
+    n = dy.dims[0]
+    classes = stride[0] * stride[1] * stride[2]
+    name = "dgrad:" + (LaunchProfiler.igemm_name(dx.voxels, dx.c) if classes == 1 else "igemm_kernel<strided classes>")
+    _PROF.run(name, 2.0 * n * dy.voxels * dy.c * dx.c * _taps(kernel), classes, go)
 
 
 def conv3d_bwd_weight(x, dy, dw, kernel, stride, ws=None):
     need = load().rx_conv3d_bwd_weight_workspace(byref(x.desc()), byref(dy.desc()), I3(*kernel))
     ws = workspace(need) if ws is None else ws
-    check(load().rx_conv3d_bwd_weight(_code(x.dtype), byref(x.desc()), byref(dy.desc()), _ptr(dw), I3(*kernel),
-                                      I3(*stride), *_ws_args(ws), stream_ptr()), "rx_conv3d_bwd_weight")
+
+    def go():
+        check(load().rx_conv3d_bwd_weight(_code(x.dtype), byref(x.desc()), byref(dy.desc()), _ptr(dw), I3(*kernel),
+                                          I3(*stride), *_ws_args(ws), stream_ptr()), "rx_conv3d_bwd_weight")
+    if _PROF is None:
+        return go()
+    n = dy.dims[0]
+    name = f"wgrad:wgrad_kernel<{64 if dy.c % 64 == 0 else 32},{64 if x.c % 64 == 0 else 32}>"
+    _PROF.run(name, 2.0 * n * dy.voxels * dy.c * x.c * _taps(kernel), 1, go)
 
 
 def convT3d_fwd(x, w_fwd, bias, y, stride, ws=None):

@@ -99,6 +99,8 @@ class Plan:
         self._x = None                        # the caller's input tensor of the current step
         self._dlogits: Dict[str, torch.Tensor] = {}
         self._grads: List[Optional[torch.Tensor]] = []
+        self.grad_order: List[int] = []       # parameter indices in the order their gradients become ready
+        self.grad_sync = None                 # optional engine.ddp.GradSync
         self._build()
 
     # ------------------------------------------------------------------ helpers
@@ -363,10 +365,19 @@ class Plan:
             return at.written or cat_written.get(id(at.act.t), False)
 
         def new_grad(idx):
-            p = P.params[idx]
-            g = torch.empty_like(p, memory_format=torch.contiguous_format)
+            # a FRESH tensor every backward (autograd may keep / accumulate into what we return); a gradient
+            # synchroniser may hand out views of its flat buckets instead (engine/ddp.py)
+            sync = P.grad_sync
+            g = sync.alloc(idx) if sync is not None else torch.empty_like(P.params[idx],
+                                                                          memory_format=torch.contiguous_format)
             P._grads[idx] = g
             return g
+
+        def done(idx):
+            if P.grad_sync is not None:
+                P.grad_sync.ready(idx)
+
+        order = self.grad_order
 
         for tape in self.dec_tapes + [self.enc_tape]:
             for rec in reversed(tape):
@@ -381,9 +392,16 @@ class Plan:
                         dl = P._dlogits.get(a["name"])
                         if dl is None:      # this task did not take part in the loss
                             gx.t.zero_()
+                            if P.grad_sync is not None:     # collectives need every rank to fill every bucket
+                                for i in (a["widx"], a["bidx"]):
+                                    new_grad(i).zero_()
+                                    done(i)
                             return
                         dw, db = new_grad(a["widx"]), new_grad(a["bidx"])
                         ops.head_bwd(dl, a["x"].act, a["w"].view(a["k"], -1), gx, dw, db)
+                        done(a["widx"])
+                        done(a["bidx"])
+                    order += [a["widx"], a["bidx"]]
                     b.append(step)
                 elif rec.kind == "inact":
                     out, y, res = a["out"], a["y"], a["res"]
@@ -410,8 +428,11 @@ class Plan:
                             ops.stem_conv_bwd_weight(P._x, dy, dw, a["kernel"])
                         else:
                             ops.conv3d_bwd_weight(a["x"].act, dy, dw, a["kernel"], a["stride"])
+                        done(a["widx"])
                         if a["bidx"] is not None:
                             ops.channel_sum(dy, new_grad(a["bidx"]))
+                            done(a["bidx"])
+                    order += [a["widx"]] + ([a["bidx"]] if a["bidx"] is not None else [])
                     b.append(wstep)
                     if rec.kind == "conv":
                         x = a["x"]
@@ -434,9 +455,12 @@ class Plan:
                     def step(a=a, gy=gy, gx=gx, acc=acc):
                         dw = new_grad(a["widx"])
                         ops.convT3d_bwd_weight(a["x"].act, gy, dw, a["stride"])
+                        done(a["widx"])
                         if a["bidx"] is not None:
                             ops.channel_sum(gy, new_grad(a["bidx"]))
+                            done(a["bidx"])
                         ops.convT3d_bwd_data(gy, a["pk"]["w_bwd"], gx, a["stride"], acc)
+                    order += [a["widx"]] + ([a["bidx"]] if a["bidx"] is not None else [])
                     b.append(step)
                 elif rec.kind == "pool":
                     x, y = a["x"], a["y"]
@@ -510,8 +534,12 @@ class Plan:
                 g = g.float().contiguous()
             self._dlogits[k] = g.unsqueeze(2) if self.two_d else g
         self._grads = [None] * len(self.params)
+        if self.grad_sync is not None:
+            self.grad_sync.begin(self)
         for step in self.bwd:
             step()
+        if self.grad_sync is not None:
+            self.grad_sync.finish()
         grads = self._grads
         self._grads = []
         return grads

@@ -1,0 +1,106 @@
+"""Task losses consumed by the train step (reference: training/losses/losses.py).  They act on the
+fp32 NCDHW logits the engine returns and stay PyTorch-ROCm ops in this round (SURVEY 8(f) rank 1
+lists a fused single-pass HIP version as the next widening step).  Same class names, constructor
+arguments and arithmetic as the reference so `_build_loss` (train.py:43-66) maps YAML names 1:1."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def flatten(tensor):
+    """(N, C, *spatial) -> (C, N * prod(spatial))   (losses.py:321-333)"""
+    c = tensor.size(1)
+    return tensor.transpose(0, 1).reshape(c, -1)
+
+
+def compute_per_channel_dice(input, target, epsilon=1e-6, weight=None):
+    """V-Net dice per channel: 2 * sum(p t) / (sum(p^2) + sum(t^2))   (losses.py:17-43)"""
+    assert input.size() == target.size(), "'input' and 'target' must have the same shape"
+    p, t = flatten(input), flatten(target).float()
+    inter = (p * t).sum(-1)
+    if weight is not None:
+        inter = weight * inter
+    den = (p * p).sum(-1) + (t * t).sum(-1)
+    return 2 * (inter / den.clamp(min=epsilon))
+
+
+class DiceLoss(nn.Module):
+    """1 - mean_c dice_c on sigmoid / softmax / raw inputs   (losses.py:95-138)"""
+
+    def __init__(self, weight=None, normalization="sigmoid"):
+        super().__init__()
+        assert normalization in ("sigmoid", "softmax", "none")
+        self.register_buffer("weight", weight)
+        self.normalization = normalization
+
+    def forward(self, input, target):
+        if self.normalization == "sigmoid":
+            input = torch.sigmoid(input)
+        elif self.normalization == "softmax":
+            input = torch.softmax(input, dim=1)
+        return 1.0 - compute_per_channel_dice(input, target, weight=self.weight).mean()
+
+
+class BCEWithLogitsLossLabelSmoothing(nn.Module):
+    """targets y -> y (1 - 2 s) + s, then BCE-with-logits   (losses.py:217-238)"""
+
+    def __init__(self, smoothing=0.1, reduction="mean"):
+        super().__init__()
+        self.smoothing, self.reduction = smoothing, reduction
+
+    def forward(self, logits, targets):
+        with torch.no_grad():
+            smoothed = targets * (1.0 - 2.0 * self.smoothing) + self.smoothing
+        return F.binary_cross_entropy_with_logits(logits, smoothed, reduction=self.reduction)
+
+
+class BCEWithLogitsLossZSmooth(nn.Module):
+    """label smoothing that grows linearly with the distance from the central Z slice (losses.py:240-304)"""
+
+    def __init__(self, center_smoothing=0.1, edge_smoothing=0.4, reduction="mean"):
+        super().__init__()
+        self.center_smoothing, self.edge_smoothing, self.reduction = center_smoothing, edge_smoothing, reduction
+
+    def forward(self, logits, targets):
+        assert logits.shape == targets.shape, "Logits and targets must match in shape."
+        d = logits.shape[2]
+        z = torch.arange(d, device=logits.device, dtype=logits.dtype)
+        ratio = (z - (d - 1) / 2.0).abs() / (d // 2)
+        alpha = (self.center_smoothing + (self.edge_smoothing - self.center_smoothing) * ratio).view(1, 1, d, 1, 1)
+        return F.binary_cross_entropy_with_logits(logits, targets * (1.0 - 2.0 * alpha) + alpha,
+                                                  reduction=self.reduction)
+
+
+class BCEDiceLoss(nn.Module):
+    """alpha * smoothed BCE + beta * Dice   (losses.py:307-318)"""
+
+    def __init__(self, alpha, beta):
+        super().__init__()
+        self.alpha, self.beta = alpha, beta
+        self.bce = BCEWithLogitsLossLabelSmoothing(smoothing=0.1, reduction="mean")
+        self.dice = DiceLoss()
+
+    def forward(self, input, target):
+        return self.alpha * self.bce(input, target) + self.beta * self.dice(input, target)
+
+
+class MaskedCosineLoss(nn.Module):
+    """1 - mean cosine similarity over voxels whose target normal is non-zero   (losses.py:187-215)"""
+
+    def forward(self, pred, target):
+        mask = (torch.norm(target, dim=1) > 1e-6).float()
+        unit = pred / torch.norm(pred, dim=1, keepdim=True).clamp(min=1e-8)
+        cos = F.cosine_similarity(unit, target, dim=1, eps=1e-8)
+        return 1.0 - (cos * mask).sum() / (mask.sum() + 1e-8)
+
+
+LOSS_FN_MAP = {
+    "BCEDiceLoss": BCEDiceLoss,
+    "BCEWithLogitsLossLabelSmoothing": BCEWithLogitsLossLabelSmoothing,
+    "BCEWithLogitsLossZSmooth": BCEWithLogitsLossZSmooth,
+    "BCEWithLogitsLoss": nn.BCEWithLogitsLoss,
+    "BCELoss": nn.BCELoss,
+    "CrossEntropyLoss": nn.CrossEntropyLoss,
+    "MSELoss": nn.MSELoss,
+    "MaskedCosineLoss": MaskedCosineLoss,
+}
