@@ -42,9 +42,10 @@ static inline ReducePlan rx_reduce_plan(long V, int C, int per16) {
   int CV = C / per16;
   int VP = 256 / CV;
   if (VP < 1) VP = 1;
-  long nch = V / 2048;
+  // ~1024 blocks per launch keep 256 CUs streaming; a block should own >= 8 passes of VP voxels
+  long nch = V / ((long)VP * 8);
   if (nch < 1) nch = 1;
-  if (nch > 1024) nch = 1024;
+  if (nch > 512) nch = 512;
   long cvx = (V + nch - 1) / nch;
   cvx = (cvx + VP - 1) / VP * VP;
   nch = (V + cvx - 1) / cvx;
@@ -64,7 +65,7 @@ static inline size_t rx_reduce_ws_bytes(int N, long V, int C, int nacc) {
 template <typename T, int NACC, typename Op>
 __global__ __launch_bounds__(256) void colreduce_kernel(Op op, int V, int C, int chunk_vox, float* __restrict__ partial) {
   constexpr int P = Elem<T>::PER16;
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // [NACC][VP][C]
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [NACC][rows][C], rows = 4 (shuffle path) or VP
   const int CV = C / P;
   const int VP = 256 / CV > 0 ? 256 / CV : 1;
   const int tid = threadIdx.x;
@@ -76,22 +77,43 @@ __global__ __launch_bounds__(256) void colreduce_kernel(Op op, int V, int C, int
     for (int j = 0; j < P; ++j) acc[a][j] = 0.f;
   const int v_begin = chunk * chunk_vox;
   const int v_end = min(V, v_begin + chunk_vox);
-  // CV may exceed 256 only if C > 256*P, rejected on the host
   const int vl = tid / CV, cv = tid - vl * CV;
   if (vl < VP) {
+    op.prepare(n, cv * P);
+#pragma unroll 4
     for (int v = v_begin + vl; v < v_end; v += VP) op.accumulate(n, v, cv * P, acc);
   }
-  if (vl < VP) {
+  const bool shuffle_path = (64 % CV) == 0;  // lanes of one wave with equal cv are CV apart
+  int rows;
+  if (shuffle_path) {
+    for (int o = CV; o < 64; o <<= 1) {
 #pragma unroll
-    for (int a = 0; a < NACC; ++a)
+      for (int a = 0; a < NACC; ++a)
 #pragma unroll
-      for (int j = 0; j < P; ++j) sm[(a * VP + vl) * C + cv * P + j] = acc[a][j];
+        for (int j = 0; j < P; ++j) acc[a][j] += __shfl_xor(acc[a][j], o, 64);
+    }
+    rows = 4;
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane < CV) {
+#pragma unroll
+      for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int j = 0; j < P; ++j) sm[(a * 4 + wave) * C + lane * P + j] = acc[a][j];
+    }
+  } else {
+    rows = VP;
+    if (vl < VP) {
+#pragma unroll
+      for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int j = 0; j < P; ++j) sm[(a * VP + vl) * C + cv * P + j] = acc[a][j];
+    }
   }
   __syncthreads();
   for (int i = tid; i < NACC * C; i += 256) {
     int a = i / C, c = i - a * C;
     float s = 0.f;
-    for (int r = 0; r < VP; ++r) s += sm[(a * VP + r) * C + c];
+    for (int r = 0; r < rows; ++r) s += sm[(a * rows + r) * C + c];
     partial[((size_t)(n * gridDim.x + chunk) * NACC + a) * C + c] = s;
   }
 }
@@ -100,26 +122,31 @@ __global__ __launch_bounds__(256) void colreduce_kernel(Op op, int V, int C, int
 enum { FIN_STATS = 0, FIN_MEAN2 = 1, FIN_SUM_OVER_N = 2 };
 // FIN_STATS: out[n][c] = (mean, rstd) from (sum, sumsq);  FIN_MEAN2: out[n][c] = (s0/V, s1/V);
 // FIN_SUM_OVER_N: out[a][c] = sum over n and chunks (NACC planes)
-__global__ void colreduce_finalize(const float* __restrict__ partial, int N, int nchunks, int nacc, int C, double V,
-                                   float eps, int mode, float* __restrict__ out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one 64-lane wave per output element: lanes stride over the chunks, xor-shuffle combine (fp64)
+__global__ __launch_bounds__(256) void colreduce_finalize(const float* __restrict__ partial, int N, int nchunks, int nacc, int C, double V,
+                                                          float eps, int mode, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // element index (wave-uniform)
   if (mode == FIN_SUM_OVER_N) {
     if (i >= nacc * C) return;
     int a = i / C, c = i - a * C;
     double s = 0.0;
-    for (int n = 0; n < N; ++n)
-      for (int k = 0; k < nchunks; ++k) s += (double)partial[((size_t)(n * nchunks + k) * nacc + a) * C + c];
-    out[i] = (float)s;
+    for (int k = lane; k < N * nchunks; k += 64) s += (double)partial[((size_t)k * nacc + a) * C + c];
+    s = wave_sum_d(s);
+    if (lane == 0) out[i] = (float)s;
     return;
   }
   if (i >= N * C) return;
   int n = i / C, c = i - n * C;
   double s0 = 0.0, s1 = 0.0;
-  for (int k = 0; k < nchunks; ++k) {
+  for (int k = lane; k < nchunks; k += 64) {
     const float* p = partial + ((size_t)(n * nchunks + k) * 2) * C + c;
     s0 += (double)p[0];
     s1 += (double)p[C];
   }
+  s0 = wave_sum_d(s0);
+  s1 = wave_sum_d(s1);
+  if (lane != 0) return;
   if (mode == FIN_STATS) {
     double mean = s0 / V;
     double var = s1 / V - mean * mean;
@@ -152,6 +179,7 @@ static inline ActView<T> make_view(const rx_act* a) {
 template <typename T>
 struct StatsOp {
   ActView<T> y;
+  __device__ inline void prepare(int, int) {}
   __device__ inline void accumulate(int n, int v, int c0, float (&acc)[2][Elem<T>::PER16]) const {
     Vec16<T> x = ld16(y.at(n, v, c0));
 #pragma unroll
@@ -189,11 +217,11 @@ extern "C" int rx_instnorm_stats(rx_dtype dt, const rx_act* y, float eps, float*
     ReducePlan p = rx_reduce_plan(V, y->c, P);
     int CV = y->c / P, VP = 256 / CV;
     StatsOp<T> op{make_view<T>(y)};
-    size_t lds = (size_t)2 * VP * y->c * sizeof(float);
+    size_t lds = (size_t)2 * (VP > 4 ? VP : 4) * y->c * sizeof(float);
     hipLaunchKernelGGL((colreduce_kernel<T, 2, StatsOp<T>>), dim3(p.nchunks, y->n), dim3(256), lds, st, op, (int)V, y->c,
                        p.chunk_vox, (float*)ws);
     int tot = y->n * y->c;
-    hipLaunchKernelGGL(colreduce_finalize, dim3((tot + 255) / 256), dim3(256), 0, st, (const float*)ws, y->n, p.nchunks, 2,
+    hipLaunchKernelGGL(colreduce_finalize, dim3((tot + 3) / 4), dim3(256), 0, st, (const float*)ws, y->n, p.nchunks, 2,
                        y->c, (double)V, eps, (int)FIN_STATS, stats);
   });
   RX_CHECK_LAUNCH("rx_instnorm_stats");
@@ -204,6 +232,7 @@ extern "C" int rx_instnorm_stats(rx_dtype dt, const rx_act* y, float eps, float*
 template <typename T>
 struct SumOp {
   ActView<T> x;
+  __device__ inline void prepare(int, int) {}
   __device__ inline void accumulate(int n, int v, int c0, float (&acc)[1][Elem<T>::PER16]) const {
     Vec16<T> a = ld16(x.at(n, v, c0));
 #pragma unroll
@@ -226,10 +255,10 @@ extern "C" int rx_channel_sum(rx_dtype dt, const rx_act* x, float* out, void* ws
     ReducePlan p = rx_reduce_plan(V, x->c, P);
     int CV = x->c / P, VP = 256 / CV;
     SumOp<T> op{make_view<T>(x)};
-    size_t lds = (size_t)VP * x->c * sizeof(float);
+    size_t lds = (size_t)(VP > 4 ? VP : 4) * x->c * sizeof(float);
     hipLaunchKernelGGL((colreduce_kernel<T, 1, SumOp<T>>), dim3(p.nchunks, x->n), dim3(256), lds, st, op, (int)V, x->c,
                        p.chunk_vox, (float*)ws);
-    hipLaunchKernelGGL(colreduce_finalize, dim3((x->c + 255) / 256), dim3(256), 0, st, (const float*)ws, x->n, p.nchunks, 1,
+    hipLaunchKernelGGL(colreduce_finalize, dim3((x->c + 3) / 4), dim3(256), 0, st, (const float*)ws, x->n, p.nchunks, 1,
                        x->c, (double)V, 0.f, (int)FIN_SUM_OVER_N, out);
   });
   RX_CHECK_LAUNCH("rx_channel_sum");
@@ -334,6 +363,14 @@ struct InBwdOp {
   int C;
   float slope;
   bool use_mask;
+  float mean[Elem<T>::PER16], rstd[Elem<T>::PER16];
+  __device__ inline void prepare(int n, int c0) {
+#pragma unroll
+    for (int j = 0; j < Elem<T>::PER16; ++j) {
+      mean[j] = stats[2 * ((size_t)n * C + c0 + j)];
+      rstd[j] = stats[2 * ((size_t)n * C + c0 + j) + 1];
+    }
+  }
   __device__ inline void accumulate(int n, int v, int c0, float (&acc)[2][Elem<T>::PER16]) const {
     constexpr int P = Elem<T>::PER16;
     Vec16<T> gv = ld16(g.at(n, v, c0));
@@ -344,8 +381,7 @@ struct InBwdOp {
     for (int j = 0; j < P; ++j) {
       float gg = Elem<T>::to_f(gv.v[j]);
       if (use_mask && !(Elem<T>::to_f(ov.v[j]) > 0.f)) gg *= slope;
-      float mean = stats[2 * ((size_t)n * C + c0 + j)], rstd = stats[2 * ((size_t)n * C + c0 + j) + 1];
-      float xh = (Elem<T>::to_f(yv.v[j]) - mean) * rstd;
+      float xh = (Elem<T>::to_f(yv.v[j]) - mean[j]) * rstd[j];
       acc[0][j] += gg;
       acc[1][j] += gg * xh;
     }
@@ -434,11 +470,11 @@ extern "C" int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y
     constexpr int P = Elem<T>::PER16;
     ReducePlan p = rx_reduce_plan(V, C, P);
     int CV = C / P, VP = 256 / CV;
-    InBwdOp<T> op{make_view<T>(g), make_view<T>(y), use_mask ? make_view<T>(out) : make_view<T>(y), stats, C, slope, use_mask};
-    size_t lds = (size_t)2 * VP * C * sizeof(float);
+    InBwdOp<T> op{make_view<T>(g), make_view<T>(y), use_mask ? make_view<T>(out) : make_view<T>(y), stats, C, slope, use_mask, {}, {}};
+    size_t lds = (size_t)2 * (VP > 4 ? VP : 4) * C * sizeof(float);
     hipLaunchKernelGGL((colreduce_kernel<T, 2, InBwdOp<T>>), dim3(p.nchunks, N), dim3(256), lds, st, op, (int)V, C, p.chunk_vox,
                        partial);
-    hipLaunchKernelGGL(colreduce_finalize, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float*)partial, N, p.nchunks, 2, C,
+    hipLaunchKernelGGL(colreduce_finalize, dim3((N * C + 3) / 4), dim3(256), 0, st, (const float*)partial, N, p.nchunks, 2, C,
                        (double)V, 0.f, (int)FIN_MEAN2, m12);
     int G = sweep_grid(V * CV, CV);
     const T* outp = use_mask ? (const T*)out->ptr : nullptr;
@@ -727,7 +763,7 @@ extern "C" int rx_head_bwd(rx_dtype dt, const float* dout_ncdhw, const rx_act* x
     size_t lds = ((size_t)k * C + (size_t)(k + 1) * VP * C) * sizeof(float);
     hipLaunchKernelGGL((head_bwd_kernel<T>), dim3(p.nchunks, N), dim3(256), lds, st, dout_ncdhw, (const T*)x->ptr, x->ld, V * x->ld, w, k,
                        dx ? (T*)dx->ptr : (T*)nullptr, dx ? dx->ld : 0, dx ? V * dx->ld : 0L, (int)V, C, p.chunk_vox, partial);
-    hipLaunchKernelGGL(colreduce_finalize, dim3(((k + 1) * C + 255) / 256), dim3(256), 0, st, (const float*)partial, N, p.nchunks, k + 1,
+    hipLaunchKernelGGL(colreduce_finalize, dim3(((k + 1) * C + 3) / 4), dim3(256), 0, st, (const float*)partial, N, p.nchunks, k + 1,
                        C, (double)V, 0.f, (int)FIN_SUM_OVER_N, fin);
     (void)hipMemcpyAsync(dw, fin, (size_t)k * C * sizeof(float), hipMemcpyDeviceToDevice, st);
     (void)hipMemcpyAsync(db, fin + (size_t)k * C, (size_t)k * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -858,9 +894,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
             float xv = 0.f;
             if ((unsigned)z2 < (unsigned)Z && (unsigned)y2 < (unsigned)Y && (unsigned)x2 < (unsigned)X)
               xv = xc[((long)z2 * Y + y2) * X + x2];
-            const int t = (a * ky + b) * kx + c;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t < 27 ? t : 0][j] += xv * d[j];
+            for (int j = 0; j < 4; ++j) acc[a * 9 + b * 3 + c][j] += xv * d[j];  // static index: stays in VGPRs
           }
         }
   }
@@ -879,19 +914,23 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
       for (int j = 0; j < 4; ++j) red[wave][t][cq * 4 + j] = acc[t][j];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < TT * Co; i += 256) {
-    int t = i / Co, co = i - t * Co;
+  (void)TT;
+  for (int i = threadIdx.x; i < 27 * Co; i += 256) {
+    int t = i / Co, co = i - t * Co;  // t = a*9 + b*3 + c slot
     float s = red[0][t][co] + red[1][t][co] + red[2][t][co] + red[3][t][co];
     partial[(((size_t)blockIdx.x * Cin + ci) * 27 + t) * Co + co] = s;
   }
 }
 
-__global__ void stem_wgrad_finalize(const float* __restrict__ partial, int nch, int Cin, int TT, int Co, float* __restrict__ dw) {
+__global__ void stem_wgrad_finalize(const float* __restrict__ partial, int nch, int Cin, int ky, int kx, int TT, int Co,
+                                    float* __restrict__ dw) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;  // over (co, ci, t) torch layout
   if (i >= Co * Cin * TT) return;
   int co = i / (Cin * TT), r = i - co * (Cin * TT), ci = r / TT, t = r - ci * TT;
+  int a = t / (ky * kx), b = (t / kx) % ky, c = t % kx;
+  int slot = a * 9 + b * 3 + c;
   double s = 0.0;
-  for (int k = 0; k < nch; ++k) s += (double)partial[(((size_t)k * Cin + ci) * 27 + t) * Co + co];
+  for (int k = 0; k < nch; ++k) s += (double)partial[(((size_t)k * Cin + ci) * 27 + slot) * Co + co];
   dw[i] = (float)s;
 }
 
@@ -922,7 +961,8 @@ extern "C" int rx_stem_conv_bwd_weight(rx_dtype dt, const float* x_ncdhw, int n,
     hipLaunchKernelGGL((stem_wgrad_kernel<T>), dim3(nch, 1, cin), dim3(256), 0, st, x_ncdhw, cin, z, y, x, (const T*)dy->ptr, dy->ld,
                        rx_act_voxels(dy) * dy->ld, Co, kernel[0], kernel[1], kernel[2], n, (int)chunk, (float*)ws);
     int tot = Co * cin * TT;
-    hipLaunchKernelGGL(stem_wgrad_finalize, dim3((tot + 255) / 256), dim3(256), 0, st, (const float*)ws, nch, cin, TT, Co, dw);
+    hipLaunchKernelGGL(stem_wgrad_finalize, dim3((tot + 255) / 256), dim3(256), 0, st, (const float*)ws, nch, cin, kernel[1], kernel[2], TT, Co,
+                       dw);
   });
   RX_CHECK_LAUNCH("rx_stem_conv_bwd_weight");
   return RX_OK;

@@ -174,15 +174,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ gt, co
   }
 }
 
-// dw[r][c][t] = sum_s slab[s][t][r][c]
+// dw[r][c][t] = sum_s slab[s][t][r][c].  A block owns 256 consecutive (r,c) pairs: reads are coalesced over
+// (r,c) for every (s,t), the [256][T] result is transposed through LDS and written as one contiguous run.
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ slab, int S, int T_, int R, int C, float* __restrict__ dw) {
+  __shared__ float tile[27 * 257];
   const long RC = (long)R * C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < RC; i += (long)gridDim.x * 256) {
-    for (int t = 0; t < T_; ++t) {
-      float s = 0.f;
+  const long base = (long)blockIdx.x * 256;
+  const long i = base + threadIdx.x;
+  for (int t = 0; t < T_; ++t) {
+    float s = 0.f;
+    if (i < RC)
       for (int k = 0; k < S; ++k) s += slab[((long)k * T_ + t) * RC + i];
-      dw[i * T_ + t] = s;
-    }
+    tile[t * 257 + threadIdx.x] = s;
+  }
+  __syncthreads();
+  const long n_here = (RC - base < 256 ? RC - base : 256) * T_;
+  for (long j = threadIdx.x; j < n_here; j += 256) {
+    int pair = (int)(j / T_), t = (int)(j - (long)pair * T_);
+    dw[base * T_ + j] = tile[t * 257 + pair];
   }
 }
 
@@ -255,8 +264,8 @@ static int wgrad_launch(rx_dtype dt, const void* gt, const void* xt, float* dw, 
   dim3 grid((g.R / BR) * (g.Cc / BC), g.ntaps, g.ksplit);
   RX_DISPATCH_DTYPE(dt, T, wgrad_dispatch<T>(BR, BC, grid, st, gt, xt, (float*)ws, g));
   long RC = (long)g.R * g.Cc;
-  int G = (int)((RC + 255) / 256 > 4096 ? 4096 : (RC + 255) / 256);
-  hipLaunchKernelGGL(wgrad_reduce, dim3(G), dim3(256), 0, st, (const float*)ws, g.ksplit, g.ntaps, g.R, g.Cc, dw);
+  hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((RC + 255) / 256)), dim3(256), 0, st, (const float*)ws, g.ksplit, g.ntaps, g.R, g.Cc,
+                     dw);
   RX_CHECK_LAUNCH("wgrad");
   return RX_OK;
 }
