@@ -195,6 +195,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ sl
   }
 }
 
+// many-splits variant (small R*C, e.g. 32x32 panels with 512 slabs): one block per (256 pairs, tap); the loop over
+// the splits is 8-way unrolled so every wave keeps 8 independent 1-KB loads in flight.  Output writes are
+// stride-T but the tensors of this regime are tiny.
+__global__ __launch_bounds__(256) void wgrad_reduce_manysplits(const float* __restrict__ slab, int S, int T_, int R, int C,
+                                                               float* __restrict__ dw) {
+  const long RC = (long)R * C;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int t = blockIdx.y;
+  if (i >= RC) return;
+  const float* p = slab + (long)t * RC + i;
+  const long stride = (long)T_ * RC;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+  int k = 0;
+  for (; k + 8 <= S; k += 8) {
+    a0 += p[(k + 0) * stride];
+    a1 += p[(k + 1) * stride];
+    a2 += p[(k + 2) * stride];
+    a3 += p[(k + 3) * stride];
+    a4 += p[(k + 4) * stride];
+    a5 += p[(k + 5) * stride];
+    a6 += p[(k + 6) * stride];
+    a7 += p[(k + 7) * stride];
+  }
+  for (; k < S; ++k) a0 += p[k * stride];
+  dw[i * T_ + t] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+}
+
 // ---------------------------------------------------------------------------------------------
 static int plan_split(const WgradGeom& g, int BR, int BC, size_t ws_bytes, int* ksplit, int* qps) {
   const long tiles = (long)(g.R / BR) * (g.Cc / BC) * g.ntaps;
@@ -252,6 +279,8 @@ static void wgrad_dispatch(int BR, int BC, dim3 grid, hipStream_t st, const void
 #undef RX_WG
 }
 
+void rx_wgrad_reduce_launch(const float* slab, int S, int T_, int R, int C, float* dw, hipStream_t st);
+
 static int wgrad_launch(rx_dtype dt, const void* gt, const void* xt, float* dw, WgradGeom& g, void* ws, size_t ws_bytes, hipStream_t st) {
   const int per16 = dt == RX_F32 ? 4 : 8;
   if (g.R % 32 || g.Cc % 32) RX_FAIL(RX_EUNSUPPORTED, "wgrad: channel counts must be multiples of 32 (R=%d C=%d)", g.R, g.Cc);
@@ -263,18 +292,29 @@ static int wgrad_launch(rx_dtype dt, const void* gt, const void* xt, float* dw, 
   if (rc) RX_FAIL(rc, "wgrad: workspace too small (%zu bytes)", ws_bytes);
   dim3 grid((g.R / BR) * (g.Cc / BC), g.ntaps, g.ksplit);
   RX_DISPATCH_DTYPE(dt, T, wgrad_dispatch<T>(BR, BC, grid, st, gt, xt, (float*)ws, g));
-  long RC = (long)g.R * g.Cc;
-  hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((RC + 255) / 256)), dim3(256), 0, st, (const float*)ws, g.ksplit, g.ntaps, g.R, g.Cc,
-                     dw);
+  rx_wgrad_reduce_launch((const float*)ws, g.ksplit, g.ntaps, g.R, g.Cc, dw, st);
   RX_CHECK_LAUNCH("wgrad");
   return RX_OK;
 }
 
 static int conv_out_dim(int in, int k, int s) { return (in + 2 * ((k - 1) / 2) - k) / s + 1; }
 
+// shared with rx_wgrad_halo.hip
+void rx_wgrad_reduce_launch(const float* slab, int S, int T_, int R, int C, float* dw, hipStream_t st) {
+  long RC = (long)R * C;
+  if (S >= 8)
+    hipLaunchKernelGGL(wgrad_reduce_manysplits, dim3((unsigned)((RC + 255) / 256), T_), dim3(256), 0, st, slab, S, T_, R, C, dw);
+  else
+    hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((RC + 255) / 256)), dim3(256), 0, st, slab, S, T_, R, C, dw);
+}
+size_t rx_wgrad_halo_ws_bytes(const rx_act* x, const rx_act* dy);
+int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
+
 extern "C" size_t rx_conv3d_bwd_weight_workspace(const rx_act* x, const rx_act* dy, const int32_t kernel[3]) {
   if (!rx_act_ok(x) || !rx_act_ok(dy)) return 0;
-  return wgrad_ws_bytes(dy->c, x->c, kernel[0] * kernel[1] * kernel[2], (long)dy->n * rx_act_voxels(dy));
+  size_t a = wgrad_ws_bytes(dy->c, x->c, kernel[0] * kernel[1] * kernel[2], (long)dy->n * rx_act_voxels(dy));
+  size_t b = (kernel[0] == 3 && kernel[1] == 3 && kernel[2] == 3) ? rx_wgrad_halo_ws_bytes(x, dy) : 0;
+  return a > b ? a : b;
 }
 
 extern "C" int rx_conv3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw, const int32_t kernel[3],
@@ -287,6 +327,11 @@ extern "C" int rx_conv3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* 
   if (dy->n != x->n || dy->z != conv_out_dim(x->z, kernel[0], stride[0]) || dy->y != conv_out_dim(x->y, kernel[1], stride[1]) ||
       dy->x != conv_out_dim(x->x, kernel[2], stride[2]))
     RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_weight: geometry mismatch");
+  if (kernel[0] == 3 && kernel[1] == 3 && kernel[2] == 3 && stride[0] == 1 && stride[1] == 1 && stride[2] == 1 && ws && dw) {
+    int rc = rx_wgrad_halo_try(dt, x, dy, dw, ws, ws_bytes, (hipStream_t)stream);  // LDS-halo kernel (16-bit types)
+    if (rc < 0) return rc;
+    if (rc == 1) return RX_OK;
+  }
   WgradGeom g;
   memset(&g, 0, sizeof(g));
   g.Qz = dy->z, g.Qy = dy->y, g.Qx = dy->x, g.Vq = (int)rx_act_voxels(dy), g.NQ = dy->n * g.Vq;

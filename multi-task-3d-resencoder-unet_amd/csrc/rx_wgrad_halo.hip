@@ -1,0 +1,263 @@
+// rx_wgrad_halo.hip -- weight gradient of the stride-1 3x3x3 convolutions (92 % of the conv FLOPs)
+// with an LDS halo tile, 16-bit types.
+//
+//   dW[t][co][ci] = sum_v dY[v][co] * X[v + d_t][ci]
+//
+// The generic kernel (rx_wgrad.hip) launches one workgroup per tap, so every X / dY voxel is fetched
+// from L2 27 times.  Here ONE workgroup owns a (32 co) x (32 ci) panel pair and ALL 27 taps:
+//   * per spatial tile (TZ x TY x TX <= 256 voxels) it stages the dY panel [VT][32] and the X halo panel
+//     [(TZ+2)(TY+2)(TX+2)][32] in LDS once (64-byte rows, zero outside the volume);
+//   * the 4 waves split the taps (7/7/7/6); per 16-voxel k-step a wave fetches the dY fragment once and one
+//     X fragment per tap -- the tap shift is just a row offset into the halo panel -- with
+//     ds_read_b64_tr_b16 (4 consecutive voxels x 16 channels per 16-lane group: any 4 consecutive 64-byte
+//     rows span all 64 banks exactly once -> conflict-free for every tap);
+//   * 7 x 32x32 fp32 accumulators per wave live in registers across ALL tiles of the workgroup's split and
+//     are written once as slab[split][tap][R][C]; the fixed-order reduce of rx_wgrad.hip finishes.
+// Two workgroups per CU (<= 62 KB LDS each) overlap one's staging with the other's MFMAs.
+#include "rx_common.h"
+
+struct WgHaloGeom {
+  int N, Z, Y, X;
+  int R, Cc, ldg, ldx;
+  long g_ss, x_ss;
+  int TZ, TY, TX, lTX, lTY;
+  int HY, HX, HV, VT;
+  int tz_n, ty_n, tx_n, NT;
+  int S, tiles_per_split, panels_c;
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_h;
+
+#define RX_WGH_MAX_HV 720
+#define RX_WGH_MAX_VT 256
+#define RX_WGH_XPIECES ((RX_WGH_MAX_HV * 4 + 255) / 256)  // 16-byte pieces of the halo panel per thread
+#define RX_WGH_GPIECES (RX_WGH_MAX_VT * 4 / 256)
+
+template <typename T>
+__device__ inline u32x4 tr_frag(const T* p0, const T* p1) {
+  s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_h*)(p0));
+  s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_h*)(p1));
+  u32x2 lo = __builtin_bit_cast(u32x2, t0), hi = __builtin_bit_cast(u32x2, t1);
+  return u32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const T* __restrict__ gt, const T* __restrict__ xt, float* __restrict__ slab,
+                                                            const WgHaloGeom g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* sG = reinterpret_cast<T*>(smem);                       // [VT][32]
+  T* sX = sG + RX_WGH_MAX_VT * 32;                          // [HV][32]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: tr reads need full EXEC
+  const int pr = blockIdx.x / g.panels_c, pc = blockIdx.x - pr * g.panels_c;
+  const int r0 = pr * 32, c0 = pc * 32;
+  const int t_begin = blockIdx.y * g.tiles_per_split;
+  const int t_end = min(g.NT, t_begin + g.tiles_per_split);
+
+  // ---- per-thread staging geometry (tile independent)
+  const int chunk = tid & 3;                                 // 16-byte chunk of a 64-byte row
+  int xh[RX_WGH_XPIECES];                                    // packed halo coordinates (hz<<16 | hy<<8 | hx), -1 = none
+#pragma unroll
+  for (int p = 0; p < RX_WGH_XPIECES; ++p) {
+    int row = (tid >> 2) + 64 * p;
+    if (row < g.HV) {
+      int hx = row % g.HX, t = row / g.HX;
+      int hy = t % g.HY, hz = t / g.HY;
+      xh[p] = (hz << 16) | (hy << 8) | hx;
+    } else
+      xh[p] = -1;
+  }
+
+  // ---- per-lane fragment geometry
+  const int g16 = lane >> 4, half = g16 & 1, h = g16 >> 1, l15 = lane & 15, q4 = l15 >> 2, p4 = l15 & 3;
+  const int coloff = 16 * half + 4 * p4;                     // element offset inside a 32-channel row
+  int toff[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    int t = wave + 4 * j;
+    int dz = t / 9 - 1, dy = (t / 3) % 3 - 1, dx = t % 3 - 1;
+    toff[j] = t < 27 ? ((dz * g.HY + dy) * g.HX + dx) * 32 : 0;
+  }
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int ksteps = g.VT >> 4;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    // tile -> (n, z0, y0, x0)
+    int tx = tile % g.tx_n, t1 = tile / g.tx_n;
+    int ty = t1 % g.ty_n, t2 = t1 / g.ty_n;
+    int tz = t2 % g.tz_n, n = t2 / g.tz_n;
+    const int z0 = tz * g.TZ, y0 = ty * g.TY, x0 = tx * g.TX;
+    const T* gn = gt + n * g.g_ss + r0;
+    const T* xn = xt + n * g.x_ss + c0;
+    // ---- stage: global -> registers
+    u32x4 gv[RX_WGH_GPIECES], xv[RX_WGH_XPIECES];
+#pragma unroll
+    for (int p = 0; p < RX_WGH_GPIECES; ++p) {
+      int v = (tid >> 2) + 64 * p;
+      u32x4 val = u32x4{0u, 0u, 0u, 0u};
+      if (v < g.VT) {
+        int vx = v & (g.TX - 1), vy = (v >> g.lTX) & (g.TY - 1), vz = v >> (g.lTX + g.lTY);
+        int z = z0 + vz, y = y0 + vy, x = x0 + vx;
+        if (z < g.Z && y < g.Y && x < g.X)
+          val = *reinterpret_cast<const u32x4*>(gn + ((long)(z * g.Y + y) * g.X + x) * g.ldg + chunk * 8);
+      }
+      gv[p] = val;
+    }
+#pragma unroll
+    for (int p = 0; p < RX_WGH_XPIECES; ++p) {
+      u32x4 val = u32x4{0u, 0u, 0u, 0u};
+      if (xh[p] >= 0) {
+        int z = z0 + (xh[p] >> 16) - 1, y = y0 + ((xh[p] >> 8) & 255) - 1, x = x0 + (xh[p] & 255) - 1;
+        if ((unsigned)z < (unsigned)g.Z && (unsigned)y < (unsigned)g.Y && (unsigned)x < (unsigned)g.X)
+          val = *reinterpret_cast<const u32x4*>(xn + ((long)(z * g.Y + y) * g.X + x) * g.ldx + chunk * 8);
+      }
+      xv[p] = val;
+    }
+    __syncthreads();  // every wave is done reading the previous tile
+#pragma unroll
+    for (int p = 0; p < RX_WGH_GPIECES; ++p) {
+      int v = (tid >> 2) + 64 * p;
+      if (v < g.VT) *reinterpret_cast<u32x4*>(sG + v * 32 + chunk * 8) = gv[p];
+    }
+#pragma unroll
+    for (int p = 0; p < RX_WGH_XPIECES; ++p) {
+      int row = (tid >> 2) + 64 * p;
+      if (xh[p] >= 0) *reinterpret_cast<u32x4*>(sX + row * 32 + chunk * 8) = xv[p];
+    }
+    __syncthreads();
+    // ---- compute: 16-voxel k-steps; this lane supplies rows (voxels) v, v+4 of its 8-voxel half
+    for (int s = 0; s < ksteps; ++s) {
+      const int v = 16 * s + 8 * h + q4;
+      const int vx = v & (g.TX - 1), vy = (v >> g.lTX) & (g.TY - 1), vz = v >> (g.lTX + g.lTY);
+      const int hr = ((vz + 1) * g.HY + (vy + 1)) * g.HX + vx + 1;  // halo row of voxel v; v+4 is hr+4 (TX >= 8)
+      int hr4;
+      if (g.TX >= 8)
+        hr4 = hr + 4;
+      else {  // TX == 4: v+4 is the next x-row
+        const int v2 = v + 4;
+        const int vy2 = (v2 >> g.lTX) & (g.TY - 1), vz2 = v2 >> (g.lTX + g.lTY);
+        hr4 = ((vz2 + 1) * g.HY + (vy2 + 1)) * g.HX + (v2 & (g.TX - 1)) + 1;
+      }
+      const u32x4 a = tr_frag<T>(sG + v * 32 + coloff, sG + (v + 4) * 32 + coloff);
+      const T* b0 = sX + hr * 32 + coloff;
+      const T* b1 = sX + hr4 * 32 + coloff;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        if (j < 6 || wave < 3) {
+          const u32x4 b = tr_frag<T>(b0 + toff[j], b1 + toff[j]);
+          Mma<T>::run(acc[j], a, b);
+        }
+      }
+    }
+  }
+
+  // ---- write the 7 accumulators: slab[split][tap][r0+row][c0+col]
+  const int col = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int t = wave + 4 * j;
+    if (t < 27) {
+      float* out = slab + (((long)blockIdx.y * 27 + t) * g.R + r0) * g.Cc + c0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+        out[(long)row * g.Cc + col] = acc[j][r];
+      }
+    }
+  }
+}
+
+static int p2ceil(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+static int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+// returns 1 and fills `g` when the halo kernel applies
+static int wgh_plan(const rx_act* x, const rx_act* dy, WgHaloGeom* g, size_t ws_bytes) {
+  memset(g, 0, sizeof(*g));
+  g->N = x->n, g->Z = x->z, g->Y = x->y, g->X = x->x;
+  g->R = dy->c, g->Cc = x->c, g->ldg = dy->ld, g->ldx = x->ld;
+  g->g_ss = rx_act_voxels(dy) * (long)dy->ld;
+  g->x_ss = rx_act_voxels(x) * (long)x->ld;
+  int TX = p2ceil(g->X);
+  TX = TX < 4 ? 4 : (TX > 16 ? 16 : TX);
+  int rem = 256 / TX;
+  int TY = p2ceil(g->Y);
+  int capy = TX == 16 ? 4 : 8;
+  if (TY > capy) TY = capy;
+  if (TY > rem) TY = rem;
+  int TZ = p2ceil(g->Z);
+  if (TZ > rem / TY) TZ = rem / TY;
+  g->TZ = TZ, g->TY = TY, g->TX = TX, g->lTX = ilog2(TX), g->lTY = ilog2(TY);
+  g->VT = TZ * TY * TX;
+  g->HY = TY + 2, g->HX = TX + 2, g->HV = (TZ + 2) * g->HY * g->HX;
+  if (g->VT < 16 || g->VT > RX_WGH_MAX_VT || g->HV > RX_WGH_MAX_HV) return 0;
+  g->tz_n = (g->Z + TZ - 1) / TZ, g->ty_n = (g->Y + TY - 1) / TY, g->tx_n = (g->X + TX - 1) / TX;
+  g->NT = g->N * g->tz_n * g->ty_n * g->tx_n;
+  g->panels_c = g->Cc / 32;
+  const long PP = (long)(g->R / 32) * g->panels_c;
+  long S = (512 + PP - 1) / PP;
+  if (S > g->NT) S = g->NT;
+  if (S < 1) S = 1;
+  const size_t slab1 = (size_t)27 * g->R * g->Cc * sizeof(float);
+  while (S > 1 && S * slab1 > ws_bytes) --S;
+  if (slab1 > ws_bytes) return 0;
+  g->tiles_per_split = (int)((g->NT + S - 1) / S);
+  g->S = (g->NT + g->tiles_per_split - 1) / g->tiles_per_split;
+  return 1;
+}
+
+size_t rx_wgrad_halo_ws_bytes(const rx_act* x, const rx_act* dy) {
+  const long PP = (long)(dy->c / 32) * (x->c / 32);
+  long S = PP > 0 ? (512 + PP - 1) / PP : 1;
+  return (size_t)S * 27 * dy->c * x->c * sizeof(float) + 256;
+}
+
+void rx_wgrad_reduce_launch(const float* slab, int S, int T_, int R, int C, float* dw, hipStream_t st);
+
+// called by rx_conv3d_bwd_weight; returns 1 if it handled the launch, 0 to fall through to the generic kernel,
+// negative on error
+int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (dt == RX_F32) return 0;
+  if (x->c % 32 || dy->c % 32 || x->ld % 8 || dy->ld % 8 || ((uintptr_t)x->ptr & 15) || ((uintptr_t)dy->ptr & 15)) return 0;
+  WgHaloGeom g;
+  if (!wgh_plan(x, dy, &g, ws_bytes)) return 0;
+  const size_t lds = (size_t)(RX_WGH_MAX_VT + RX_WGH_MAX_HV) * 64;
+  dim3 grid((g.R / 32) * g.panels_c, g.S);
+  if (dt == RX_BF16) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL((wgrad_halo_kernel<bf16_t>), grid, dim3(256), lds, st, (const bf16_t*)dy->ptr, (const bf16_t*)x->ptr, (float*)ws, g);
+  } else {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL((wgrad_halo_kernel<f16_t>), grid, dim3(256), lds, st, (const f16_t*)dy->ptr, (const f16_t*)x->ptr, (float*)ws, g);
+  }
+  rx_wgrad_reduce_launch((const float*)ws, g.S, 27, g.R, g.Cc, dw, st);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    rx_set_error("wgrad_halo: %s", hipGetErrorString(e));
+    return RX_ELAUNCH;
+  }
+  return 1;
+}
