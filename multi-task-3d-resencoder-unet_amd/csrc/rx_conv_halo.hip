@@ -1,0 +1,266 @@
+// rx_conv_halo.hip -- forward / backward-data of the stride-1 3x3x3 convolutions with an LDS halo tile.
+//
+//   Out[v][co] (+)= sum_t sum_ci W[t][co][ci] * In[v + d_t][ci] (+ bias),   d_t = t-1 (fwd) or 1-t (bwd-data)
+//
+// The generic gather kernel (rx_igemm.hip) re-stages a [voxels][64 B] activation tile for every (tap, channel
+// chunk): 27 global->LDS round trips per chunk, each only 8 MFMAs deep -> latency bound (~17 % of MFMA peak).
+// Here a workgroup owns an output tile of TZ x TY x TX = 256 voxels x BN channels and, per 64-byte input-channel
+// chunk, stages the (TZ+2)(TY+2)(TX+2) halo rows ONCE; all 27 taps read it with a row offset.  Weights are
+// streamed in three dz-planes of 9 taps ([9][BN][64 B] in LDS).  Phases (chunk, dz-plane) are software
+// pipelined: the global loads of phase p+1 are in flight in registers while phase p runs 36..72 MFMAs per wave,
+// and two workgroups share a CU (<= 80 KB LDS each).
+// MFMA orientation and epilogue are those of rx_igemm.hip (weights = A operand, voxels = accumulator lanes).
+#include "rx_common.h"
+
+struct ConvHaloGeom {
+  int N, Z, Y, X;
+  int Ci, Co, ldi, ldo;
+  long in_ss, out_ss;
+  int TZ, TY, TX, lTX, lTY;
+  int HY, HX, HV, VT;
+  int tz_n, ty_n, tx_n, NT;
+  int accumulate, flip;
+};
+
+#define RX_CH_MAX_HV 656   // (4,4,16): 648 rows, (4,8,8)/(8,8,4): 600; 2 workgroups of <= 79 KB per CU
+#define RX_CH_XPIECES ((RX_CH_MAX_HV * 4 + 255) / 256)
+
+__device__ inline int hswz(int row, int chunk) { return row * 4 + (chunk ^ ((row >> 2) & 3)); }
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256, 2) void conv_halo_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
+                                                           T* __restrict__ out, const ConvHaloGeom g) {
+  constexpr int P = Elem<T>::PER16;
+  constexpr int KB = 4 * P;             // input channels per 64-byte chunk
+  constexpr int NB = BN / 32;
+  constexpr int MV = 2;                 // voxel blocks per wave (VT = 256)
+  constexpr int WPIECES = (9 * BN * 4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* sX = reinterpret_cast<u32x4*>(smem);                   // [HV][4 chunks]
+  u32x4* sW = sX + RX_CH_MAX_HV * 4;                            // [9][BN][4 chunks]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x, n0 = blockIdx.y * BN;
+  int tx = tile % g.tx_n, t1 = tile / g.tx_n;
+  int ty = t1 % g.ty_n, t2 = t1 / g.ty_n;
+  int tz = t2 % g.tz_n, n = t2 / g.tz_n;
+  const int z0 = tz * g.TZ, y0 = ty * g.TY, x0 = tx * g.TX;
+  const T* in_n = in + (long)n * g.in_ss;
+
+  // ---- staging geometry of this thread: halo rows (tid>>2)+64p, chunk tid&3; global offset or -1 (zero fill)
+  const int chunk = tid & 3;
+  int xoff[RX_CH_XPIECES];
+#pragma unroll
+  for (int p = 0; p < RX_CH_XPIECES; ++p) {
+    int row = (tid >> 2) + 64 * p;
+    xoff[p] = -2;  // not a halo row
+    if (row < g.HV) {
+      int hx = row % g.HX, t = row / g.HX;
+      int hy = t % g.HY, hz = t / g.HY;
+      int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+      bool ok = (unsigned)z < (unsigned)g.Z && (unsigned)y < (unsigned)g.Y && (unsigned)x < (unsigned)g.X;
+      xoff[p] = ok ? (int)(((long)(z * g.Y + y) * g.X + x) * g.ldi) + chunk * P : -1;
+    }
+  }
+  const int nchunks = g.Ci / KB;
+  const int nphase = nchunks * 3;
+
+  u32x4 xr[RX_CH_XPIECES], wr[WPIECES];
+  auto prefetch = [&](int ph) {
+    const int cc = ph / 3, dzg = ph - cc * 3;
+    if (dzg == 0) {
+#pragma unroll
+      for (int p = 0; p < RX_CH_XPIECES; ++p) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (xoff[p] >= 0) v = *reinterpret_cast<const u32x4*>(in_n + xoff[p] + cc * KB);
+        xr[p] = v;
+      }
+    }
+    // weights of taps 9*dzg .. 9*dzg+8 (flip: the plane of taps whose dz offset is the same)
+#pragma unroll
+    for (int p = 0; p < WPIECES; ++p) {
+      int i = tid + 256 * p;          // piece index: ((tl*BN + row)*4 + chunk)
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (i < 9 * BN * 4) {
+        int c4 = i & 3, r = (i >> 2) % BN, tl = (i >> 2) / BN;
+        int t = 9 * dzg + tl;
+        v = *reinterpret_cast<const u32x4*>(w + ((long)t * g.Co + n0 + r) * g.Ci + cc * KB + c4 * P);
+      }
+      wr[p] = v;
+    }
+  };
+  auto commit = [&](int ph) {
+    const int dzg = ph % 3;
+    if (dzg == 0) {
+#pragma unroll
+      for (int p = 0; p < RX_CH_XPIECES; ++p) {
+        int row = (tid >> 2) + 64 * p;
+        if (xoff[p] != -2) sX[hswz(row, chunk)] = xr[p];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < WPIECES; ++p) {
+      int i = tid + 256 * p;
+      if (i < 9 * BN * 4) {
+        int c4 = i & 3, rr = i >> 2;  // rr = tl*BN + r
+        sW[hswz(rr, c4)] = wr[p];
+      }
+    }
+  };
+
+  // ---- fragment geometry: this lane's voxel in each of its MV blocks -> halo row
+  const int fr = lane & 31, fh = lane >> 5;
+  int hrow[MV];
+#pragma unroll
+  for (int b = 0; b < MV; ++b) {
+    int v = (wave * MV + b) * 32 + fr;
+    int vx = v & (g.TX - 1), vy = (v >> g.lTX) & (g.TY - 1), vz = v >> (g.lTX + g.lTY);
+    hrow[b] = ((vz + 1) * g.HY + (vy + 1)) * g.HX + vx + 1;
+  }
+  const int sgn = g.flip ? -1 : 1;
+
+  f32x16 acc[NB][MV];
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b < MV; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  prefetch(0);
+  for (int ph = 0; ph < nphase; ++ph) {
+    __syncthreads();  // previous phase fully consumed
+    commit(ph);
+    __syncthreads();
+    if (ph + 1 < nphase) prefetch(ph + 1);
+    const int dzg = ph % 3;
+    const int dz = sgn * (dzg - 1);
+#pragma unroll
+    for (int tl = 0; tl < 9; ++tl) {
+      const int dy = sgn * (tl / 3 - 1), dx = sgn * (tl % 3 - 1);
+      const int toff = (dz * g.HY + dy) * g.HX + dx;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 af[NB], bf[MV];
+#pragma unroll
+        for (int a = 0; a < NB; ++a) af[a] = sW[hswz(tl * BN + a * 32 + fr, ks * 2 + fh)];
+#pragma unroll
+        for (int b = 0; b < MV; ++b) bf[b] = sX[hswz(hrow[b] + toff, ks * 2 + fh)];
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+          for (int b = 0; b < MV; ++b) Mma<T>::run(acc[a][b], af[a], bf[b]);
+      }
+    }
+  }
+
+  // ---- epilogue (as rx_igemm.hip): lane = voxel, 4 runs of 4 consecutive channels per 32-block
+#pragma unroll
+  for (int b = 0; b < MV; ++b) {
+    int v = (wave * MV + b) * 32 + fr;
+    int vx = v & (g.TX - 1), vy = (v >> g.lTX) & (g.TY - 1), vz = v >> (g.lTX + g.lTY);
+    int z = z0 + vz, y = y0 + vy, x = x0 + vx;
+    if (z >= g.Z || y >= g.Y || x >= g.X) continue;
+    T* op = out + (long)n * g.out_ss + ((long)(z * g.Y + y) * g.X + x) * g.ldo + n0;
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int co = a * 32 + 8 * g4 + 4 * fh;
+        T vals[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float f = acc[a][b][4 * g4 + i];
+          if (bias) f += bias[n0 + co + i];
+          if (g.accumulate) f += Elem<T>::to_f(op[co + i]);
+          vals[i] = Elem<T>::from_f(f);
+        }
+        if (sizeof(T) == 2)
+          *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
+        else
+          *reinterpret_cast<u32x4*>(op + co) = *reinterpret_cast<u32x4*>(vals);
+      }
+  }
+}
+
+static int ch_p2ceil(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+static int ch_ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+template <typename T>
+static void ch_dispatch(int BN, dim3 grid, hipStream_t st, const void* in, const void* w, const float* bias, void* out,
+                        const ConvHaloGeom& g) {
+  if (BN == 64) {
+    const size_t lds = (size_t)(RX_CH_MAX_HV * 4 + 9 * 64 * 4) * 16;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<T, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL((conv_halo_kernel<T, 64>), grid, dim3(256), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g);
+  } else {
+    const size_t lds = (size_t)(RX_CH_MAX_HV * 4 + 9 * 32 * 4) * 16;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<T, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL((conv_halo_kernel<T, 32>), grid, dim3(256), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g);
+  }
+}
+
+// returns 1 if handled, 0 to fall through to the generic kernel, negative on error.
+// in/out: same spatial dims (stride 1, kernel 3x3x3, padding 1).  flip = 1 for backward-data.
+int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* bias, const rx_act* out, int flip, int accumulate,
+                     hipStream_t st) {
+  const int per16 = dt == RX_F32 ? 4 : 8;
+  const int KB = 4 * per16;
+  if (in->c % KB || out->c % 32 || in->ld % per16 || out->ld % 4) return 0;
+  if (((uintptr_t)in->ptr & 15) || ((uintptr_t)out->ptr & 7) || ((uintptr_t)w & 15)) return 0;
+  if (rx_act_voxels(in) * (long)in->ld >= (1L << 31)) return 0;  // 32-bit halo offsets
+  ConvHaloGeom g;
+  memset(&g, 0, sizeof(g));
+  g.N = in->n, g.Z = in->z, g.Y = in->y, g.X = in->x;
+  g.Ci = in->c, g.Co = out->c, g.ldi = in->ld, g.ldo = out->ld;
+  g.in_ss = rx_act_voxels(in) * (long)in->ld;
+  g.out_ss = rx_act_voxels(out) * (long)out->ld;
+  int TX = ch_p2ceil(g.X);
+  TX = TX < 4 ? 4 : (TX > 16 ? 16 : TX);
+  int rem = 256 / TX;
+  int TY = ch_p2ceil(g.Y);
+  int capy = TX == 16 ? 4 : 8;
+  if (TY > capy) TY = capy;
+  if (TY > rem) TY = rem;
+  int TZ = ch_p2ceil(g.Z);
+  if (TZ > rem / TY) TZ = rem / TY;
+  if (TZ * TY * TX != 256) return 0;  // the kernel is written for full 256-voxel tiles
+  g.TZ = TZ, g.TY = TY, g.TX = TX, g.lTX = ch_ilog2(TX), g.lTY = ch_ilog2(TY);
+  g.VT = 256;
+  g.HY = TY + 2, g.HX = TX + 2, g.HV = (TZ + 2) * g.HY * g.HX;
+  if (g.HV > RX_CH_MAX_HV) return 0;
+  g.tz_n = (g.Z + TZ - 1) / TZ, g.ty_n = (g.Y + TY - 1) / TY, g.tx_n = (g.X + TX - 1) / TX;
+  g.NT = g.N * g.tz_n * g.ty_n * g.tx_n;
+  g.accumulate = accumulate, g.flip = flip;
+  const int BN = (g.Co % 64 == 0) ? 64 : 32;
+  if ((long)g.NT * (g.Co / BN) < 192) return 0;  // too few workgroups: the split-K gather kernel fills the chip better
+  dim3 grid(g.NT, g.Co / BN);
+  switch (dt) {
+    case RX_F32: ch_dispatch<float>(BN, grid, st, in->ptr, w, bias, out->ptr, g); break;
+    case RX_BF16: ch_dispatch<bf16_t>(BN, grid, st, in->ptr, w, bias, out->ptr, g); break;
+    case RX_F16: ch_dispatch<f16_t>(BN, grid, st, in->ptr, w, bias, out->ptr, g); break;
+    default: return 0;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    rx_set_error("conv_halo: %s", hipGetErrorString(e));
+    return RX_ELAUNCH;
+  }
+  return 1;
+}

@@ -262,6 +262,13 @@ static int igemm_launch(rx_dtype dt, const void* in, const void* w, const float*
   return RX_OK;
 }
 
+// rx_conv_halo.hip
+int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* bias, const rx_act* out, int flip, int accumulate,
+                     hipStream_t st);
+static bool is_333_s1(const int32_t k[3], const int32_t s[3]) {
+  return k[0] == 3 && k[1] == 3 && k[2] == 3 && s[0] == 1 && s[1] == 1 && s[2] == 1;
+}
+
 static int check13(const int32_t k[3], const int32_t s[3], const char* who) {
   for (int i = 0; i < 3; ++i) {
     if (k[i] != 1 && k[i] != 3) RX_FAIL(RX_EUNSUPPORTED, "%s: kernel sizes must be 1 or 3", who);
@@ -288,6 +295,11 @@ extern "C" int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, co
   if (y->n != x->n || y->z != conv_out_dim(x->z, kernel[0], stride[0]) || y->y != conv_out_dim(x->y, kernel[1], stride[1]) ||
       y->x != conv_out_dim(x->x, kernel[2], stride[2]))
     RX_FAIL(RX_EINVAL, "rx_conv3d_fwd: output geometry mismatch");
+  if (is_333_s1(kernel, stride)) {
+    rc = rx_conv_halo_try(dt, x, w_fwd, bias, y, 0, 0, (hipStream_t)stream);  // LDS-halo kernel
+    if (rc < 0) return rc;
+    if (rc == 1) return RX_OK;
+  }
   IgemmGeom g;
   memset(&g, 0, sizeof(g));
   geom_in(g, x);
@@ -315,6 +327,11 @@ extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_b
   if (dy->n != dx->n || dy->z != conv_out_dim(dx->z, kernel[0], stride[0]) || dy->y != conv_out_dim(dx->y, kernel[1], stride[1]) ||
       dy->x != conv_out_dim(dx->x, kernel[2], stride[2]))
     RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_data: geometry mismatch");
+  if (is_333_s1(kernel, stride)) {
+    rc = rx_conv_halo_try(dt, dy, w_bwd, nullptr, dx, 1, accumulate, (hipStream_t)stream);
+    if (rc < 0) return rc;
+    if (rc == 1) return RX_OK;
+  }
   const int k[3] = {kernel[0], kernel[1], kernel[2]}, s[3] = {stride[0], stride[1], stride[2]};
   const int p[3] = {(k[0] - 1) / 2, (k[1] - 1) / 2, (k[2] - 1) / 2};
   const int din[3] = {dx->z, dx->y, dx->x};
