@@ -1,0 +1,232 @@
+"""`BaseTrainer` -- the reference's trainer plug-in surface (train.py:19-339) around the HIP engine.
+
+Same constructor and overridable hooks (`_build_model`, `_configure_dataset`, `_build_loss`, `_get_optimizer`,
+`_get_scheduler`, `_get_scaler`, `_configure_dataloaders`, `train`), same loop semantics (gradient
+accumulation flush condition incl. the reference's `len(train_dataloader)` quirk, `clip_grad_norm_(…, 3)`,
+per-epoch checkpoint dict {'model','optimizer','scheduler','epoch'} pruned to 10, validation each epoch,
+CosineAnnealingLR stepped per epoch, final `<model_name>_final.pth`).  Differences, all documented in DESIGN.md:
+  * no `torch.compile` (the engine is one opaque autograd boundary) -> checkpoint keys carry no `_orig_mod.`;
+    a reference checkpoint with that prefix is accepted on load;
+  * `tr_config.amp_dtype` ("bf16" default | "fp16" | "fp32") picks the autocast dtype; a GradScaler is only
+    enabled for fp16;
+  * launched under `torch.distributed.run` it becomes data parallel (RCCL all-reduce overlapped with backward,
+    engine/ddp.py) -- the reference is single-GPU;
+  * the CLI passes arguments by keyword (the reference swaps `verbose` / `debug_dataloader` positionally);
+  * TensorBoard / debug GIFs are optional extras and skipped when their packages are missing.
+"""
+import os
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.optim import SGD, AdamW
+from torch.optim.lr_scheduler import CosineAnnealingLR
+from torch.utils.data import DataLoader, SubsetRandomSampler
+
+from .builders.build_network_from_config import NetworkFromConfig
+from .configuration.config_manager import ConfigManager
+from .dataloading.dataset import SyntheticPatchDataset, ZarrSegmentationDataset3D
+from .engine.ddp import GradSync, broadcast_parameters
+from .training.losses.losses import LOSS_FN_MAP
+
+_AMP = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}
+
+
+class BaseTrainer:
+    def __init__(self, config_file: str, verbose: bool = True, debug_dataloader: bool = False):
+        self.mgr = ConfigManager(config_file, verbose=verbose)
+        self.verbose = verbose
+        self.debug_dataloader = debug_dataloader
+        self.world = int(os.environ.get("WORLD_SIZE", 1))
+        self.rank = int(os.environ.get("RANK", 0))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", 0))
+        self.last_patches_per_sec = None
+
+    # ---- hooks ----------------------------------------------------------------------------------
+    def _build_model(self):
+        return NetworkFromConfig(self.mgr)
+
+    def _configure_dataset(self):
+        if self.mgr.dataset_config.get("synthetic", False) or not self.mgr.volume_paths:
+            return SyntheticPatchDataset(self.mgr)
+        return ZarrSegmentationDataset3D(self.mgr)
+
+    def _build_loss(self):
+        fns = {}
+        for name, info in self.mgr.tasks.items():
+            key = info.get("loss_fn", "BCEDiceLoss")
+            if key not in LOSS_FN_MAP:
+                raise ValueError(f"Loss function {key} not found in LOSS_FN_MAP. Add it to the mapping and try again.")
+            fns[name] = LOSS_FN_MAP[key](**info.get("loss_kwargs", {}))
+        return fns
+
+    def _get_optimizer(self, model):
+        if self.mgr.optimizer == "SGD":
+            return SGD(model.parameters(), lr=self.mgr.initial_lr, momentum=0.9, nesterov=True,
+                       weight_decay=self.mgr.weight_decay)
+        return AdamW(model.parameters(), lr=self.mgr.initial_lr, weight_decay=self.mgr.weight_decay)
+
+    def _get_scheduler(self, optimizer):
+        return CosineAnnealingLR(optimizer, T_max=self.mgr.max_epoch, eta_min=0)
+
+    def _get_scaler(self):
+        return torch.amp.GradScaler("cuda", enabled=self._amp_name() == "fp16")
+
+    def _configure_dataloaders(self, dataset):
+        n = len(dataset)
+        idx = list(range(n))
+        np.random.shuffle(idx)
+        split = int(np.floor(self.mgr.tr_val_split * n))
+        tr, va = idx[:split], idx[split:] or idx[-1:]
+        if self.world > 1:                               # each rank trains on its own slice
+            tr = tr[self.rank::self.world]
+        workers = self.mgr.train_num_dataloader_workers
+        train = DataLoader(dataset, batch_size=self.mgr.train_batch_size, sampler=SubsetRandomSampler(tr),
+                           pin_memory=True, num_workers=workers)
+        val = DataLoader(dataset, batch_size=1, sampler=SubsetRandomSampler(va), pin_memory=True, num_workers=workers)
+        return train, val
+
+    # ---- helpers ----------------------------------------------------------------------------------
+    def _amp_name(self):
+        return str(self.mgr.tr_configs.get("amp_dtype", "bf16")).lower()
+
+    @staticmethod
+    def _strip_compile_prefix(sd):
+        return {(k[len("_orig_mod."):] if k.startswith("_orig_mod.") else k): v for k, v in sd.items()}
+
+    def _log(self, *a):
+        if self.rank == 0:
+            print(*a, flush=True)
+
+    # ---- training loop ----------------------------------------------------------------------------
+    def train(self):
+        if self.world > 1 and not dist.is_initialized():
+            torch.cuda.set_device(self.local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+        device = torch.device("cuda", self.local_rank if self.world > 1 else torch.cuda.current_device())
+        model = self._build_model()
+        optimizer = self._get_optimizer(model)
+        loss_fns = self._build_loss()
+        dataset = self._configure_dataset()
+        scheduler = self._get_scheduler(optimizer)
+        scaler = self._get_scaler()
+        model = model.to(device)
+        amp_dtype = _AMP[self._amp_name()]
+        sync = None
+        if self.world > 1:
+            broadcast_parameters(model)
+            sync = GradSync()
+        train_loader, val_loader = self._configure_dataloaders(dataset)
+        if self.debug_dataloader:
+            self._log("debug_dataloader: shapes of one item:", {k: tuple(v.shape) for k, v in dataset[0].items()})
+            return
+
+        start_epoch = 0
+        ckpt_dir = Path(self.mgr.ckpt_out_base)
+        if self.rank == 0:
+            os.makedirs(ckpt_dir, exist_ok=True)
+        if self.mgr.checkpoint_path is not None and Path(self.mgr.checkpoint_path).exists():
+            self._log(f"Loading checkpoint from {self.mgr.checkpoint_path}")
+            ck = torch.load(self.mgr.checkpoint_path, map_location=device, weights_only=True)
+            model.load_state_dict(self._strip_compile_prefix(ck["model"]))
+            if not self.mgr.load_weights_only:
+                optimizer.load_state_dict(ck["optimizer"])
+                scheduler.load_state_dict(ck["scheduler"])
+                start_epoch = ck["epoch"] + 1
+            else:
+                scheduler = self._get_scheduler(optimizer)
+
+        writer = None
+        if self.rank == 0:
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+                writer = SummaryWriter(log_dir=self.mgr.tensorboard_log_dir)
+            except Exception:
+                writer = None
+        accum = self.mgr.gradient_accumulation
+        params = [p for p in model.parameters()]
+
+        def forward_loss(batch, train_mode):
+            x = batch["image"].to(device, dtype=torch.float32, non_blocking=True)
+            targets = {k: v.to(device, dtype=torch.float32, non_blocking=True) for k, v in batch.items() if k != "image"}
+            with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+                out = model(x)
+                if sync is not None:
+                    for plan in model._plans.values():
+                        plan.grad_sync = sync
+                total, per = 0.0, {}
+                for name, gt in targets.items():
+                    l = loss_fns[name](out[name], gt)
+                    if train_mode:
+                        l = l * self.mgr.tasks[name].get("weight", 1.0)
+                    total = total + l
+                    per[name] = l.detach()
+            return total, per, x.shape[0]
+
+        for epoch in range(start_epoch, self.mgr.max_epoch):
+            model.train()
+            running = {t: 0.0 for t in self.mgr.tasks}
+            steps, patches = 0, 0
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for i, batch in enumerate(train_loader):
+                if i >= self.mgr.max_steps_per_epoch:
+                    break
+                total, per, bsz = forward_loss(batch, True)
+                scaler.scale(total / accum).backward()
+                if (i + 1) % accum == 0 or (i + 1) == len(train_loader):
+                    torch.nn.utils.clip_grad_norm_(params, 3)
+                    scaler.step(optimizer)
+                    scaler.update()
+                    optimizer.zero_grad(set_to_none=True)
+                for k, v in per.items():
+                    running[k] += float(v)
+                steps += 1
+                patches += bsz
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            self.last_patches_per_sec = patches * self.world / max(dt, 1e-9)
+            desc = " | ".join(f"{k}: {running[k] / max(steps, 1):.4f}" for k in running)
+            self._log(f"[Train] Epoch {epoch + 1} => {desc} | {self.last_patches_per_sec:.2f} patches/s")
+            if writer is not None:
+                for k in running:
+                    writer.add_scalar(f"train/{k}_loss", running[k] / max(steps, 1), epoch)
+
+            if self.rank == 0:
+                torch.save({"model": model.state_dict(), "optimizer": optimizer.state_dict(),
+                            "scheduler": scheduler.state_dict(), "epoch": epoch},
+                           f"{ckpt_dir}/{self.mgr.model_name}_{epoch + 1}.pth")
+                ckpts = sorted(ckpt_dir.glob(f"{self.mgr.model_name}_*.pth"), key=lambda p: p.stat().st_mtime)
+                while len(ckpts) > 10:
+                    ckpts.pop(0).unlink()
+
+            model.eval()
+            with torch.no_grad():
+                vrun, vsteps = {t: 0.0 for t in self.mgr.tasks}, 0
+                for i, batch in enumerate(val_loader):
+                    if i >= self.mgr.max_val_steps_per_epoch:
+                        break
+                    _, per, _ = forward_loss(batch, False)
+                    for k, v in per.items():
+                        vrun[k] += float(v)
+                    vsteps += 1
+                for k in vrun:
+                    self._log(f"Task '{k}', epoch {epoch + 1} avg val loss: {vrun[k] / max(vsteps, 1):.4f}")
+            scheduler.step()
+
+        self._log("Training Finished!")
+        if self.rank == 0:
+            torch.save(model.state_dict(), f"{self.mgr.model_name}_final.pth")
+        return model
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser(description="Train script for the multi-task 3-D ResEnc U-Net (HIP engine).")
+    ap.add_argument("--config_path", type=str, required=True)
+    ap.add_argument("--debug_dataloader", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    BaseTrainer(a.config_path, verbose=a.verbose, debug_dataloader=a.debug_dataloader).train()
