@@ -43,6 +43,28 @@ WORKLOADS = {
 }
 
 
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/*pmc_hbm_traffic.json: FETCH_SIZE x2 x1024 + WRITE_SIZE x1024, see scripts/pmc_traffic.py)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))
+    if not files:
+        return None
+    try:
+        data = json.load(open(files[-1]))
+    except Exception:
+        return None
+    base = kernel_label.split(":")[-1]                 # e.g. conv_halo_kernel<64>, wgrad_halo_kernel, igemm_kernel<256,64>
+    name = base.split("<")[0]
+    args = base.split("<")[1].rstrip(">").split(",") if "<" in base else []
+    want = "".join(f"Li{a}E" for a in args)
+    for k, v in data.items():
+        if name in k and "DF16b" in k and want in k:
+            return dict(bytes_per_launch=v["read_bytes_per_launch"] + v["write_bytes_per_launch"],
+                        read=v["read_bytes_per_launch"], write=v["write_bytes_per_launch"], source=os.path.basename(files[-1]))
+    return None
+
+
 def make_mgr(w):
     from types import SimpleNamespace
     return SimpleNamespace(tasks=w["tasks"], train_patch_size=tuple(w["patch"]), train_batch_size=w["batch"],
@@ -228,8 +250,10 @@ def main():
                 dom = max(groups, key=lambda k: groups[k]["ms"])
                 g = groups[dom]
                 ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+                tr = pmc_traffic(dom) if args.dtype == "bf16" else None
                 roofline = dict(bound="mfma", kernel=dom, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
-                                traffic=None, avg_us_per_launch=g["ms"] * 1e3 / max(g["launches"], 1),
+                                traffic=tr["bytes_per_launch"] if tr else None, traffic_detail=tr,
+                                avg_us_per_launch=g["ms"] * 1e3 / max(g["launches"], 1),
                                 flops_per_launch=g["flops"] / max(g["launches"], 1))
         line = {
             "metric": "train patches/sec (b,c,z,y,x) ResEncM 1x128^3", "value": value, "unit": "patches/s",

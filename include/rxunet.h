@@ -47,6 +47,8 @@ typedef struct {
 int rx_abi_version(void);
 const char* rx_last_error(void);
 int rx_device_arch_ok(void); /* 1 iff the current device is gfx950 */
+/* name of the kernel instantiation the last conv / convT entry point of this thread launched (bench attribution) */
+const char* rx_last_conv_kernel(void);
 
 /* ---- parameter packing ------------------------------------------------------------------ */
 /* Conv3d weight (Co,Ci,T) fp32 -> w_fwd [T][Co][Ci] and w_bwd [T][Ci][Co] (same tap order; the

@@ -23,6 +23,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // ---- error plumbing (host) -----------------------------------------------------------------
 void rx_set_error(const char* fmt, ...);
+void rx_note_kernel(const char* name);   // records which kernel instantiation the last conv entry point used
 #define RX_FAIL(code, ...)      \
   do {                          \
     rx_set_error(__VA_ARGS__);  \

@@ -251,6 +251,7 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   const int BN = (g.Co % 64 == 0) ? 64 : 32;
   if ((long)g.NT * (g.Co / BN) < 192) return 0;  // too few workgroups: the split-K gather kernel fills the chip better
   dim3 grid(g.NT, g.Co / BN);
+  rx_note_kernel(BN == 64 ? "conv_halo_kernel<64>" : "conv_halo_kernel<32>");
   switch (dt) {
     case RX_F32: ch_dispatch<float>(BN, grid, st, in->ptr, w, bias, out->ptr, g); break;
     case RX_BF16: ch_dispatch<bf16_t>(BN, grid, st, in->ptr, w, bias, out->ptr, g); break;

@@ -20,6 +20,9 @@ void rx_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* rx_last_error(void) { return g_err; }
+static thread_local const char* g_last_kernel = "";
+void rx_note_kernel(const char* name) { g_last_kernel = name; }
+extern "C" const char* rx_last_conv_kernel(void) { return g_last_kernel; }
 extern "C" int rx_abi_version(void) { return 1; }
 extern "C" int rx_device_arch_ok(void) {
   int dev = 0;

@@ -213,6 +213,8 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(const float* __restri
 template <typename T>
 static void igemm_dispatch_tile(int BM, int BN, dim3 grid, hipStream_t st, const void* in, const void* w, const float* bias, void* out,
                                 void* ws, const IgemmGeom& g, int N, int ks) {
+  rx_note_kernel(BM == 256 ? (BN == 64 ? "igemm_kernel<256,64>" : "igemm_kernel<256,32>")
+                            : (BN == 64 ? "igemm_kernel<128,64>" : "igemm_kernel<128,32>"));
   if (BM == 256 && BN == 64)
     hipLaunchKernelGGL((igemm_kernel<T, 256, 64>), grid, dim3(256), 0, st, (const T*)in, (const T*)w, bias, (T*)out, (float*)ws, g);
   else if (BM == 256 && BN == 32)

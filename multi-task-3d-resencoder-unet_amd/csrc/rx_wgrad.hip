@@ -291,6 +291,7 @@ static int wgrad_launch(rx_dtype dt, const void* gt, const void* xt, float* dw, 
   int rc = plan_split(g, BR, BC, ws_bytes, &g.ksplit, &g.q_per_split);
   if (rc) RX_FAIL(rc, "wgrad: workspace too small (%zu bytes)", ws_bytes);
   dim3 grid((g.R / BR) * (g.Cc / BC), g.ntaps, g.ksplit);
+  rx_note_kernel(BR == 64 ? (BC == 64 ? "wgrad_kernel<64,64>" : "wgrad_kernel<64,32>") : (BC == 64 ? "wgrad_kernel<32,64>" : "wgrad_kernel<32,32>"));
   RX_DISPATCH_DTYPE(dt, T, wgrad_dispatch<T>(BR, BC, grid, st, gt, xt, (float*)ws, g));
   rx_wgrad_reduce_launch((const float*)ws, g.ksplit, g.ntaps, g.R, g.Cc, dw, st);
   RX_CHECK_LAUNCH("wgrad");

@@ -236,6 +236,7 @@ int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw,
   if (!wgh_plan(x, dy, &g, ws_bytes)) return 0;
   const size_t lds = (size_t)(RX_WGH_MAX_VT + RX_WGH_MAX_HV) * 64;
   dim3 grid((g.R / 32) * g.panels_c, g.S);
+  rx_note_kernel("wgrad_halo_kernel");
   if (dt == RX_BF16) {
     static bool attr = false;
     if (!attr) {

@@ -31,6 +31,7 @@ _SIGNATURES = {
     "rx_abi_version": (c_int, []),
     "rx_last_error": (c_char_p, []),
     "rx_device_arch_ok": (c_int, []),
+    "rx_last_conv_kernel": (c_char_p, []),
     "rx_pack_conv_weight": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rx_pack_convT_weight": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rx_conv_workspace_hint": (c_size_t, []),
