@@ -10,6 +10,8 @@
 // pipelined: the global loads of phase p+1 are in flight in registers while phase p runs 36..72 MFMAs per wave,
 // and two workgroups share a CU (<= 80 KB LDS each).
 // MFMA orientation and epilogue are those of rx_igemm.hip (weights = A operand, voxels = accumulator lanes).
+#include <stdlib.h>
+
 #include "rx_common.h"
 
 struct ConvHaloGeom {
@@ -19,7 +21,7 @@ struct ConvHaloGeom {
   int TZ, TY, TX, lTX, lTY;
   int HY, HX, HV, VT;
   int tz_n, ty_n, tx_n, NT;
-  int accumulate, flip;
+  int accumulate, flip, dbg;  // dbg: ablation mask (RX_DBG env): 1 no halo loads, 2 no weight loads, 4 no MFMA, 8 no stores
 };
 
 #define RX_CH_MAX_HV 656   // (4,4,16): 648 rows, (4,8,8)/(8,8,4): 600; 2 workgroups of <= 79 KB per CU
@@ -183,6 +185,185 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const T* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Specialisation for the full-resolution layers (Co block of 32, tile 4x4x16): everything about the tile is a
+// compile-time constant, halo rows are padded to 80 bytes (16 consecutive rows hit 16 distinct 16-byte bank
+// slots: (20*r mod 64) is a bijection on r mod 16) so the LDS address of (voxel, tap, k-step) is
+// lane_base + CONSTANT and folds into the ds_read_b128 offset field -- no address arithmetic in the MFMA loop
+// (the generic kernel above spends ~14 VALU instructions per MFMA on XOR-swizzled addresses).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
+                                                             T* __restrict__ out, const ConvHaloGeom g) {
+  constexpr int P = Elem<T>::PER16;
+  constexpr int KB = 4 * P;
+  constexpr int TZ = 4, TY = 4, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;  // 648 rows
+  constexpr int ROWB = 80;                     // bytes per halo row (64 payload + 16 pad)
+  constexpr int XPIECES = (HV * 4 + 255) / 256;  // 11
+  constexpr int WPIECES = (9 * 32 * 4 + 255) / 256;  // 5
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sX = smem;                    // [HV][80 B]
+  unsigned char* sW = smem + HV * ROWB;        // [9][32][64 B], chunk XOR (row>>2)&3
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x, n0 = blockIdx.y * 32;
+  const int tx = tile % g.tx_n, t1 = tile / g.tx_n;
+  const int ty = t1 % g.ty_n, t2 = t1 / g.ty_n;
+  const int tz = t2 % g.tz_n, n = t2 / g.tz_n;
+  const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+  const T* in_n = in + (long)n * g.in_ss;
+  const int chunk = tid & 3;
+
+  int xoff[XPIECES];  // element offset of this thread's halo pieces, -1 = zero fill, -2 = no such row
+#pragma unroll
+  for (int p = 0; p < XPIECES; ++p) {
+    const int row = (tid >> 2) + 64 * p;
+    xoff[p] = -2;
+    if (row < HV) {
+      const int hx = row % HX, t = row / HX, hy = t % HY, hz = t / HY;
+      const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+      const bool ok = (unsigned)z < (unsigned)g.Z && (unsigned)y < (unsigned)g.Y && (unsigned)x < (unsigned)g.X;
+      xoff[p] = ok ? (int)(((long)(z * g.Y + y) * g.X + x) * g.ldi) + chunk * P : -1;
+    }
+  }
+  const int nchunks = g.Ci / KB, nphase = nchunks * 3;
+  u32x4 xr[XPIECES], wr[WPIECES];
+  auto prefetch = [&](int ph) {
+    const int cc = ph / 3, dzg = ph - cc * 3;
+    if (dzg == 0) {
+#pragma unroll
+      for (int p = 0; p < XPIECES; ++p) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (xoff[p] >= 0 && !(g.dbg & 1)) v = *reinterpret_cast<const u32x4*>(in_n + xoff[p] + cc * KB);
+        xr[p] = v;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < WPIECES; ++p) {
+      const int i = tid + 256 * p;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (i < 9 * 32 * 4 && !(g.dbg & 2)) {
+        const int c4 = i & 3, r = (i >> 2) & 31, tl = i >> 7;
+        v = *reinterpret_cast<const u32x4*>(w + ((long)(9 * dzg + tl) * g.Co + n0 + r) * g.Ci + cc * KB + c4 * P);
+      }
+      wr[p] = v;
+    }
+  };
+  auto commit = [&](int ph) {
+    if (ph % 3 == 0) {
+#pragma unroll
+      for (int p = 0; p < XPIECES; ++p) {
+        const int row = (tid >> 2) + 64 * p;
+        if (xoff[p] != -2) *reinterpret_cast<u32x4*>(sX + row * ROWB + chunk * 16) = xr[p];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < WPIECES; ++p) {
+      const int i = tid + 256 * p;
+      if (i < 9 * 32 * 4) {
+        const int c4 = i & 3, rr = i >> 2;
+        *reinterpret_cast<u32x4*>(sW + rr * 64 + ((c4 ^ ((rr >> 2) & 3)) << 4)) = wr[p];
+      }
+    }
+  };
+
+  // lane bases (bytes).  voxel v = (wave*2+b)*32 + fr, x fastest: vx = v&15, vy = (v>>4)&3, vz = v>>6
+  const int fr = lane & 31, fh = lane >> 5;
+  const unsigned char* xb[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int v = (wave * 2 + b) * 32 + fr;
+    const int vx = v & 15, vy = (v >> 4) & 3, vz = v >> 6;
+    xb[b] = sX + (((vz + 1) * HY + (vy + 1)) * HX + vx + 1) * ROWB + fh * 16;
+  }
+  const int wsw = (fr >> 2) & 3;                         // weight-row swizzle term of this lane
+  const unsigned char* wb0 = sW + fr * 64 + (((0 + fh) ^ wsw) << 4);  // k-step 0
+  const unsigned char* wb1 = sW + fr * 64 + (((2 + fh) ^ wsw) << 4);  // k-step 1
+  const int sgn = g.flip ? -1 : 1;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  prefetch(0);
+  for (int ph = 0; ph < nphase; ++ph) {
+    __syncthreads();
+    commit(ph);
+    __syncthreads();
+    if (ph + 1 < nphase) prefetch(ph + 1);
+    const int dzoff = sgn * ((ph % 3) - 1) * (HY * HX * ROWB);  // wave-uniform byte offset of this dz plane
+    const unsigned char* x0p = xb[0] + dzoff;
+    const unsigned char* x1p = xb[1] + dzoff;
+    if (g.dbg & 4) {
+    } else if (sgn > 0) {
+#pragma unroll
+      for (int tl = 0; tl < 9; ++tl) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int toff = ((tl / 3 - 1) * HX + (tl % 3 - 1)) * ROWB;  // compile-time after unrolling
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const u32x4 a = *reinterpret_cast<const u32x4*>((ks ? wb1 : wb0) + tl * 32 * 64);
+          const u32x4 b0 = *reinterpret_cast<const u32x4*>(x0p + toff + ks * 32);
+          const u32x4 b1 = *reinterpret_cast<const u32x4*>(x1p + toff + ks * 32);
+          Mma<T>::run(acc[0], a, b0);
+          Mma<T>::run(acc[1], a, b1);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int tl = 0; tl < 9; ++tl) {
+        const int toff = -((tl / 3 - 1) * HX + (tl % 3 - 1)) * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const u32x4 a = *reinterpret_cast<const u32x4*>((ks ? wb1 : wb0) + tl * 32 * 64);
+          const u32x4 b0 = *reinterpret_cast<const u32x4*>(x0p + toff + ks * 32);
+          const u32x4 b1 = *reinterpret_cast<const u32x4*>(x1p + toff + ks * 32);
+          Mma<T>::run(acc[0], a, b0);
+          Mma<T>::run(acc[1], a, b1);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int v = (wave * 2 + b) * 32 + fr;
+    const int z = z0 + (v >> 6), y = y0 + ((v >> 4) & 3), x = x0 + (v & 15);
+    if (z >= g.Z || y >= g.Y || x >= g.X || (g.dbg & 8)) continue;
+    T* op = out + (long)n * g.out_ss + ((long)(z * g.Y + y) * g.X + x) * g.ldo + n0;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int co = 8 * g4 + 4 * fh;
+      T vals[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float f = acc[b][4 * g4 + i];
+        if (bias) f += bias[n0 + co + i];
+        if (g.accumulate) f += Elem<T>::to_f(op[co + i]);
+        vals[i] = Elem<T>::from_f(f);
+      }
+      if (sizeof(T) == 2)
+        *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
+      else
+        *reinterpret_cast<u32x4*>(op + co) = *reinterpret_cast<u32x4*>(vals);
+    }
+  }
+}
+
+template <typename T>
+static void ch32_launch(dim3 grid, hipStream_t st, const void* in, const void* w, const float* bias, void* out, const ConvHaloGeom& g) {
+  const size_t lds = (size_t)648 * 80 + (size_t)9 * 32 * 64;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv_halo32_kernel<T>), grid, dim3(256), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g);
+}
+
 static int ch_p2ceil(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -248,9 +429,32 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   g.tz_n = (g.Z + TZ - 1) / TZ, g.ty_n = (g.Y + TY - 1) / TY, g.tx_n = (g.X + TX - 1) / TX;
   g.NT = g.N * g.tz_n * g.ty_n * g.tx_n;
   g.accumulate = accumulate, g.flip = flip;
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("RX_DBG");
+      dbg = e ? atoi(e) : 0;
+    }
+    g.dbg = dbg;
+  }
   const int BN = (g.Co % 64 == 0) ? 64 : 32;
   if ((long)g.NT * (g.Co / BN) < 192) return 0;  // too few workgroups: the split-K gather kernel fills the chip better
   dim3 grid(g.NT, g.Co / BN);
+  if (BN == 32 && TZ == 4 && TY == 4 && TX == 16) {  // full-resolution layers: compile-time tile, padded rows
+    rx_note_kernel("conv_halo32_kernel");
+    switch (dt) {
+      case RX_F32: ch32_launch<float>(grid, st, in->ptr, w, bias, out->ptr, g); break;
+      case RX_BF16: ch32_launch<bf16_t>(grid, st, in->ptr, w, bias, out->ptr, g); break;
+      case RX_F16: ch32_launch<f16_t>(grid, st, in->ptr, w, bias, out->ptr, g); break;
+      default: return 0;
+    }
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) {
+      rx_set_error("conv_halo32: %s", hipGetErrorString(e2));
+      return RX_ELAUNCH;
+    }
+    return 1;
+  }
   rx_note_kernel(BN == 64 ? "conv_halo_kernel<64>" : "conv_halo_kernel<32>");
   switch (dt) {
     case RX_F32: ch_dispatch<float>(BN, grid, st, in->ptr, w, bias, out->ptr, g); break;
