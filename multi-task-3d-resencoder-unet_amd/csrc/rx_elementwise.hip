@@ -937,6 +937,8 @@ __global__ void stem_wgrad_finalize(const float* __restrict__ partial, int nch, 
   dw[i] = (float)s;
 }
 
+int rx_stem_wgrad_mfma_try(rx_dtype dt, const float* x, int n, int cin, int z, int y, int xx, const rx_act* dy, const int32_t kernel[3],
+                           float* partial, int max_blocks, int* nblocks_out, hipStream_t st);
 #define RX_STEM_CHUNKS 1024
 extern "C" size_t rx_stem_conv_bwd_weight_workspace(int cin, int cout, int taps) {
   (void)taps;
@@ -953,6 +955,18 @@ extern "C" int rx_stem_conv_bwd_weight(rx_dtype dt, const float* x_ncdhw, int n,
   if (Co > 64 || Co % 4 || 64 % (Co / 4)) RX_FAIL(RX_EUNSUPPORTED, "rx_stem_conv_bwd_weight: Cout must be 4,8,16,32 or 64 (got %d)", Co);
   if (dy->n != n || dy->z != z || dy->y != y || dy->x != x) RX_FAIL(RX_EINVAL, "rx_stem_conv_bwd_weight: geometry mismatch");
   if (ws_bytes < rx_stem_conv_bwd_weight_workspace(cin, Co, 27)) RX_FAIL(RX_EWORKSPACE, "rx_stem_conv_bwd_weight: workspace too small");
+  hipStream_t st0 = (hipStream_t)stream;
+  {
+    int nb = 0;
+    if (rx_stem_wgrad_mfma_try(dt, x_ncdhw, n, cin, z, y, x, dy, kernel, (float*)ws, RX_STEM_CHUNKS, &nb, st0) == 1) {
+      const int TT0 = kernel[0] * kernel[1] * kernel[2];
+      int tot0 = Co * cin * TT0;
+      hipLaunchKernelGGL(stem_wgrad_finalize, dim3((tot0 + 255) / 256), dim3(256), 0, st0, (const float*)ws, nb, cin, kernel[1], kernel[2],
+                         TT0, Co, dw);
+      RX_CHECK_LAUNCH("rx_stem_conv_bwd_weight(mfma)");
+      return RX_OK;
+    }
+  }
   const long NV = (long)n * z * y * x;
   const int VPB = 256 / (Co / 4);
   long chunk = (NV + RX_STEM_CHUNKS - 1) / RX_STEM_CHUNKS;

@@ -1,0 +1,152 @@
+// rx_stem_wgrad.hip -- weight gradient of the stem convolution (Cin <= 4 input channels, NCDHW fp32 image) on MFMA,
+// 16-bit compute types:   dW[co][ci][t] = sum_v dY[v][co] * x[ci][v + t - 1]
+//
+// GEMM view: M = Cout (32-row blocks), N = 27 taps (padded to 32 columns), K = voxels.  A = dY^T comes from the
+// LDS tile [256 voxels][Cout] through ds_read_b64_tr_b16 (as in rx_wgrad_halo.hip); the B fragment of lane
+// (tap, k-half) is 8 consecutive x-values of the fp32 halo tile shifted by the tap, converted to the compute
+// dtype in registers.  Tile 4x4x16 voxels, 4 waves take 4 k-steps each, accumulators persist over all tiles of a
+// workgroup; partials [block][ci][slot=a*9+b*3+c][co] are summed by stem_wgrad_finalize (rx_elementwise.hip).
+// (fp32 mode keeps the exact VALU kernel of rx_elementwise.hip.)
+#include "rx_common.h"
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_s;
+
+template <typename T>
+__device__ inline u32x4 pack8(const float (&f)[8]) {
+  T v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = Elem<T>::from_f(f[j]);
+  return *reinterpret_cast<u32x4*>(v);
+}
+
+template <typename T, int NB>
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __restrict__ x, int Cin, int N, int Z, int Y, int X,
+                                                              const T* __restrict__ dy, int ldy, long sy, int kz, int ky, int kx,
+                                                              int tiles_per_block, float* __restrict__ partial) {
+  constexpr int TZ = 4, TY = 4, TX = 16, HY = TY + 2, HX = TX + 2, HV = (TZ + 2) * HY * HX;  // 648
+  constexpr int CO = NB * 32;
+  __shared__ __attribute__((aligned(16))) T sG[256 * CO];
+  __shared__ float sX[4][HV + 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tz_n = (Z + TZ - 1) / TZ, ty_n = (Y + TY - 1) / TY, tx_n = (X + TX - 1) / TX;
+  const int NT = N * tz_n * ty_n * tx_n;
+  const int t_begin = blockIdx.x * tiles_per_block, t_end = min(NT, t_begin + tiles_per_block);
+  const long V = (long)Z * Y * X;
+  const int pz = (kz - 1) / 2, py = (ky - 1) / 2, px = (kx - 1) / 2;
+
+  // B-operand geometry: column = tap slot (a*9+b*3+c), valid if inside the kernel extent
+  const int tap = lane & 31, h = lane >> 5;
+  const int ta = tap / 9, tb = (tap / 3) % 3, tc = tap % 3;
+  const bool tap_ok = tap < 27 && ta < kz && tb < ky && tc < kx;
+  const int toff = tap_ok ? ((ta - pz) * HY + (tb - py)) * HX + (tc - px) : 0;
+  // A-operand geometry (tr read)
+  const int g16 = lane >> 4, half = g16 & 1, ah = g16 >> 1, l15 = lane & 15, q4 = l15 >> 2, p4 = l15 & 3;
+
+  f32x16 acc[4][NB];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][a][r] = 0.f;
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int tx = tile % tx_n, t1 = tile / tx_n;
+    int ty = t1 % ty_n, t2 = t1 / ty_n;
+    int tz = t2 % tz_n, n = t2 / tz_n;
+    const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+    __syncthreads();
+    // dY tile: 256 voxels x CO channels, 16-byte pieces
+    for (int i = tid; i < 256 * CO / 8; i += 256) {
+      const int v = i / (CO / 8), cv = i - v * (CO / 8);
+      const int z = z0 + (v >> 6), y = y0 + ((v >> 4) & 3), xx = x0 + (v & 15);
+      u32x4 val = u32x4{0u, 0u, 0u, 0u};
+      if (z < Z && y < Y && xx < X) val = *reinterpret_cast<const u32x4*>(dy + n * sy + ((long)(z * Y + y) * X + xx) * ldy + cv * 8);
+      // panel layout [32-channel panel][voxel][32]
+      const int c = cv * 8;
+      *reinterpret_cast<u32x4*>(sG + ((c >> 5) * 256 + v) * 32 + (c & 31)) = val;
+    }
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* xc = x + ((long)n * Cin + ci) * V;
+      for (int i = tid; i < HV; i += 256) {
+        const int hx = i % HX, t = i / HX, hy = t % HY, hz = t / HY;
+        const int z = z0 + hz - 1, y = y0 + hy - 1, xx = x0 + hx - 1;
+        float v = 0.f;
+        if ((unsigned)z < (unsigned)Z && (unsigned)y < (unsigned)Y && (unsigned)xx < (unsigned)X) v = xc[((long)z * Y + y) * X + xx];
+        sX[ci][i] = v;
+      }
+    }
+    __syncthreads();
+    // this wave's 4 k-steps (16 voxels each = one x-row of the tile)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int s = wave * 4 + kk;                 // k-step = tile row (z = s>>2, y = s&3)
+      const int hrow = (((s >> 2) + 1) * HY + ((s & 3) + 1)) * HX + 1;  // halo index of x = 0 of that row
+      u32x4 af[NB];
+#pragma unroll
+      for (int a = 0; a < NB; ++a) {
+        const T* p0 = sG + (a * 256 + 16 * s + 8 * ah + q4) * 32 + 16 * half + 4 * p4;
+        s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_s*)(p0));
+        s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_s*)(p0 + 4 * 32));
+        u32x2 lo = __builtin_bit_cast(u32x2, t0), hi = __builtin_bit_cast(u32x2, t1);
+        af[a] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+      }
+      for (int ci = 0; ci < Cin; ++ci) {
+        float f[8];
+        const float* bp = &sX[ci][hrow + 8 * h + toff];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = tap_ok ? bp[j] : 0.f;
+        const u32x4 bf = pack8<T>(f);
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          if (ci == 0) Mma<T>::run(acc[0][a], af[a], bf);
+          if (ci == 1) Mma<T>::run(acc[1][a], af[a], bf);
+          if (ci == 2) Mma<T>::run(acc[2][a], af[a], bf);
+          if (ci == 3) Mma<T>::run(acc[3][a], af[a], bf);
+        }
+      }
+    }
+  }
+  // combine the 4 waves through LDS (reuse sG as float scratch is too small for NB=2: use a dedicated buffer)
+  __shared__ float red[4][32][33];
+  const int col = lane & 31, fh = lane >> 5;
+  for (int ci = 0; ci < Cin; ++ci)
+    for (int a = 0; a < NB; ++a) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;   // row = output channel, col = tap slot
+        float v = ci == 0 ? acc[0][a][r] : ci == 1 ? acc[1][a][r] : ci == 2 ? acc[2][a][r] : acc[3][a][r];
+        red[wave][row][col] = v;
+      }
+      __syncthreads();
+      for (int i = tid; i < 27 * 32; i += 256) {
+        const int t = i >> 5, co = i & 31;
+        float s = red[0][co][t] + red[1][co][t] + red[2][co][t] + red[3][co][t];
+        partial[(((size_t)blockIdx.x * Cin + ci) * 27 + t) * CO + a * 32 + co] = s;
+      }
+    }
+}
+
+// returns 1 if handled (16-bit dtypes, Cout 32 or 64), 0 otherwise; nblocks_out = number of partial blocks written
+int rx_stem_wgrad_mfma_try(rx_dtype dt, const float* x, int n, int cin, int z, int y, int xx, const rx_act* dy, const int32_t kernel[3],
+                           float* partial, int max_blocks, int* nblocks_out, hipStream_t st) {
+  if (dt == RX_F32 || (dy->c != 32 && dy->c != 64) || dy->ld % 8 || ((uintptr_t)dy->ptr & 15) || cin > 4) return 0;
+  const int NT = n * ((z + 3) / 4) * ((y + 3) / 4) * ((xx + 15) / 16);
+  int blocks = NT < max_blocks ? NT : max_blocks;
+  if (blocks > 1024) blocks = 1024;
+  const int per = (NT + blocks - 1) / blocks;
+  blocks = (NT + per - 1) / per;
+  const long sy = rx_act_voxels(dy) * (long)dy->ld;
+#define RX_SW(TT, NBB)                                                                                                           \
+  hipLaunchKernelGGL((stem_wgrad_mfma_kernel<TT, NBB>), dim3(blocks), dim3(256), 0, st, x, cin, n, z, y, xx, (const TT*)dy->ptr, \
+                     dy->ld, sy, kernel[0], kernel[1], kernel[2], per, partial)
+  if (dt == RX_BF16) {
+    if (dy->c == 32) RX_SW(bf16_t, 1); else RX_SW(bf16_t, 2);
+  } else {
+    if (dy->c == 32) RX_SW(f16_t, 1); else RX_SW(f16_t, 2);
+  }
+#undef RX_SW
+  *nblocks_out = blocks;
+  return 1;
+}

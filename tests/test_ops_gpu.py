@@ -206,7 +206,8 @@ def test_stem(ops, dtype, cin, k):
     assert rel(oa.to_ncdhw(), ref.detach()) < TOL[dtype]
     dw = torch.empty((co, cin, *k), dtype=torch.float32, device="cuda")
     ops.stem_conv_bwd_weight(xd, to_act(ops, g, dtype), dw, k)
-    assert rel(dw, wr.grad) < 2e-5
+    # 16-bit modes run the MFMA kernel, which rounds the image to the compute dtype (fp32 mode stays exact)
+    assert rel(dw, wr.grad) < (2e-5 if dtype == torch.float32 else TOL[dtype])
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
