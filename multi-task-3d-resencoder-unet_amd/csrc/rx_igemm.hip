@@ -20,18 +20,28 @@
 #include "rx_common.h"
 
 
-struct IgemmGeom {
+// One launch covers up to 8 PHASES that share input / output / weights but differ in iteration grid, output
+// phase offset and tap list: the 8 output parity classes of a stride-2 backward-data, or the 8 kernel positions
+// of a k=s=2 transposed convolution (previously 8 launches of ~10 us each).
+struct IgemmPhase {
   int Qz, Qy, Qx, Vq;
+  int opz, opy, opx;
+  int tap0, ntaps;
+  int mtile0, mtiles;
+  long slab_off;  // element offset of this phase's split-K slabs
+};
+
+struct IgemmGeom {
   int Zi, Yi, Xi, Ci, ldi;
   long in_ss;
   int isz, isy, isx;
   int Zo, Yo, Xo, Co, ldo;
   long out_ss;
-  int osz, osy, osx, opz, opy, opx;
-  int ntaps, accumulate, ksplit, mtiles;
-  RxTap taps[27];
+  int osz, osy, osx;
+  int accumulate, ksplit, nph, total_mtiles;
+  IgemmPhase ph[8];
+  RxTap taps[32];
 };
-
 
 __device__ inline int swz(int row, int chunk) { return row * 4 + (chunk ^ ((row >> 2) & 3)); }
 
@@ -48,7 +58,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ in, co
   __shared__ u32x4 sW[2][BN * 4];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mtile = blockIdx.x % g.mtiles, split = blockIdx.x / g.mtiles;
+  const int mt_all = blockIdx.x % g.total_mtiles, split = blockIdx.x / g.total_mtiles;
+  int phase = 0;
+  for (int i = 1; i < g.nph; ++i)
+    if (mt_all >= g.ph[i].mtile0) phase = i;
+  const IgemmPhase P_ = g.ph[phase];
+  const int mtile = mt_all - P_.mtile0;
   const int m0 = mtile * BM, n0 = blockIdx.y * BN, n = blockIdx.z;
   const T* in_n = in + (long)n * g.in_ss;
 
@@ -59,22 +74,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ in, co
 #pragma unroll
   for (int p = 0; p < XP; ++p) {
     int q = m0 + (tid >> 2) + 64 * p;
-    rok[p] = q < g.Vq;
-    int qx = q % g.Qx, t = q / g.Qx;
-    int qy = t % g.Qy, qz = t / g.Qy;
+    rok[p] = q < P_.Vq;
+    int qx = q % P_.Qx, t = q / P_.Qx;
+    int qy = t % P_.Qy, qz = t / P_.Qy;
     rz[p] = qz * g.isz;
     ry[p] = qy * g.isy;
     rx[p] = qx * g.isx;
   }
   const int nkc = g.Ci / KB;
-  const int nkt_all = g.ntaps * nkc;
+  const int nkt_all = P_.ntaps * nkc;
   const int kt_begin = (int)((long)nkt_all * split / g.ksplit);
   const int kt_end = (int)((long)nkt_all * (split + 1) / g.ksplit);
 
   u32x4 xr[XP], wr[WP];
   auto load_tile = [&](int kt) {
     const int tap = kt / nkc, cc = kt - tap * nkc;
-    const RxTap tp = g.taps[tap];
+    const RxTap tp = g.taps[P_.tap0 + tap];
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
       int z = rz[p] + tp.dz, y = ry[p] + tp.dy, x = rx[p] + tp.dx;
@@ -138,9 +153,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ in, co
 #pragma unroll
   for (int b = 0; b < MV; ++b) {
     const int q = m0 + wave * (BM / 4) + b * 32 + fr;
-    if (q >= g.Vq) continue;
+    if (q >= P_.Vq) continue;
     if (g.ksplit > 1) {
-      float* sp = slab + (((long)split * gridDim.z + n) * g.Vq + q) * g.Co + n0;
+      float* sp = slab + P_.slab_off + (((long)split * gridDim.z + n) * P_.Vq + q) * g.Co + n0;
 #pragma unroll
       for (int a = 0; a < NB; ++a)
 #pragma unroll
@@ -150,9 +165,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ in, co
         }
       continue;
     }
-    int qx = q % g.Qx, t = q / g.Qx;
-    int qy = t % g.Qy, qz = t / g.Qy;
-    long ov = ((long)(qz * g.osz + g.opz) * g.Yo + (qy * g.osy + g.opy)) * g.Xo + (qx * g.osx + g.opx);
+    int qx = q % P_.Qx, t = q / P_.Qx;
+    int qy = t % P_.Qy, qz = t / P_.Qy;
+    long ov = ((long)(qz * g.osz + P_.opz) * g.Yo + (qy * g.osy + P_.opy)) * g.Xo + (qx * g.osx + P_.opx);
     T* op = out + (long)n * g.out_ss + ov * g.ldo + n0;
 #pragma unroll
     for (int a = 0; a < NB; ++a)
@@ -175,21 +190,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ in, co
   }
 }
 
-// split-K reduce: out[q*os+op][c] (+)= sum_s slab[s][n][q][c] (+ bias)
+// split-K reduce: out[q*os+op][c] (+)= sum_s slab[s][n][q][c] (+ bias); blockIdx.y = phase
 template <typename T>
 __global__ __launch_bounds__(256) void igemm_splitk_reduce(const float* __restrict__ slab, const float* __restrict__ bias, T* __restrict__ out,
                                                            const IgemmGeom g, int N) {
+  const IgemmPhase P_ = g.ph[blockIdx.y];
   const int CV = g.Co / 4;
-  const long total = (long)N * g.Vq * CV;
+  const long total = (long)N * P_.Vq * CV;
+  const float* sl = slab + P_.slab_off;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     int cv = (int)(i % CV);
     long nq = i / CV;
-    int q = (int)(nq % g.Vq), n = (int)(nq / g.Vq);
+    int q = (int)(nq % P_.Vq), n = (int)(nq / P_.Vq);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < g.ksplit; ++k) s += *reinterpret_cast<const f32x4*>(slab + (((long)k * N + n) * g.Vq + q) * g.Co + cv * 4);
-    int qx = q % g.Qx, t = q / g.Qx;
-    int qy = t % g.Qy, qz = t / g.Qy;
-    long ov = ((long)(qz * g.osz + g.opz) * g.Yo + (qy * g.osy + g.opy)) * g.Xo + (qx * g.osx + g.opx);
+    for (int k = 0; k < g.ksplit; ++k) s += *reinterpret_cast<const f32x4*>(sl + (((long)k * N + n) * P_.Vq + q) * g.Co + cv * 4);
+    int qx = q % P_.Qx, t = q / P_.Qx;
+    int qy = t % P_.Qy, qz = t / P_.Qy;
+    long ov = ((long)(qz * g.osz + P_.opz) * g.Yo + (qy * g.osy + P_.opy)) * g.Xo + (qx * g.osx + P_.opx);
     T* op = out + (long)n * g.out_ss + ov * g.ldo + cv * 4;
     T vals[4];
 #pragma unroll
@@ -224,9 +241,11 @@ static void igemm_dispatch_tile(int BM, int BN, dim3 grid, hipStream_t st, const
   else
     hipLaunchKernelGGL((igemm_kernel<T, 128, 32>), grid, dim3(256), 0, st, (const T*)in, (const T*)w, bias, (T*)out, (float*)ws, g);
   if (ks > 1) {
-    long total = (long)N * g.Vq * (g.Co / 4);
+    int vmax = 0;
+    for (int i = 0; i < g.nph; ++i) vmax = g.ph[i].Vq > vmax ? g.ph[i].Vq : vmax;
+    long total = (long)N * vmax * (g.Co / 4);
     int G = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-    hipLaunchKernelGGL((igemm_splitk_reduce<T>), dim3(G), dim3(256), 0, st, (const float*)ws, bias, (T*)out, g, N);
+    hipLaunchKernelGGL((igemm_splitk_reduce<T>), dim3(G, g.nph), dim3(256), 0, st, (const float*)ws, bias, (T*)out, g, N);
   }
 }
 
@@ -238,27 +257,44 @@ static int igemm_launch(rx_dtype dt, const void* in, const void* w, const float*
   if (g.Co % 32) RX_FAIL(RX_EUNSUPPORTED, "igemm: output channels must be a multiple of 32 (got %d)", g.Co);
   if (g.ldi % per16 || g.ldo % 4 || ((uintptr_t)in & 15) || ((uintptr_t)out & 7) || ((uintptr_t)w & 15))
     RX_FAIL(RX_EUNSUPPORTED, "igemm: misaligned operand (ldi=%d ldo=%d)", g.ldi, g.ldo);
-  if (g.Vq <= 0) return RX_OK;
+  int vmax = 0, nkt_max = 0;
+  for (int i = 0; i < g.nph; ++i) {
+    vmax = g.ph[i].Vq > vmax ? g.ph[i].Vq : vmax;
+    nkt_max = g.ph[i].ntaps > nkt_max ? g.ph[i].ntaps : nkt_max;
+  }
+  nkt_max *= g.Ci / KB;
+  if (vmax <= 0 || g.nph <= 0) return RX_OK;
   const int BN = (g.Co % 64 == 0) ? 64 : 32;
-  const int BM = (g.Vq <= 128) ? 128 : 256;
-  g.mtiles = (g.Vq + BM - 1) / BM;
+  const int BM = (vmax <= 128) ? 128 : 256;
+  g.total_mtiles = 0;
+  long vsum = 0;
+  for (int i = 0; i < g.nph; ++i) {
+    g.ph[i].mtile0 = g.total_mtiles;
+    g.ph[i].mtiles = (g.ph[i].Vq + BM - 1) / BM;
+    g.total_mtiles += g.ph[i].mtiles;
+    vsum += g.ph[i].Vq;
+  }
   // split-K when the natural grid cannot fill the chip and K is deep
-  const long wgs = (long)g.mtiles * (g.Co / BN) * N;
-  const int nkt = g.ntaps * (g.Ci / KB);
+  const long wgs = (long)g.total_mtiles * (g.Co / BN) * N;
   int ks = 1;
-  if (wgs < 192 && nkt >= 16 && ws) {
+  if (wgs < 192 && nkt_max >= 16 && ws) {
     ks = (int)((512 + wgs - 1) / wgs);
-    if (ks > nkt / 4) ks = nkt / 4;
+    if (ks > nkt_max / 4) ks = nkt_max / 4;
     if (ks > 32) ks = 32;
-    size_t need = (size_t)ks * N * g.Vq * g.Co * sizeof(float);
+    size_t need = (size_t)ks * N * vsum * g.Co * sizeof(float);
     while (ks > 1 && need > ws_bytes) {
       --ks;
-      need = (size_t)ks * N * g.Vq * g.Co * sizeof(float);
+      need = (size_t)ks * N * vsum * g.Co * sizeof(float);
     }
     if (ks < 1) ks = 1;
   }
+  long off = 0;
+  for (int i = 0; i < g.nph; ++i) {
+    g.ph[i].slab_off = off;
+    off += (long)ks * N * g.ph[i].Vq * g.Co;
+  }
   g.ksplit = ks;
-  dim3 grid(g.mtiles * ks, g.Co / BN, N);
+  dim3 grid(g.total_mtiles * ks, g.Co / BN, N);
   RX_DISPATCH_DTYPE(dt, T, igemm_dispatch_tile<T>(BM, BN, grid, st, in, w, bias, out, ws, g, N, ks));
   RX_CHECK_LAUNCH("igemm");
   return RX_OK;
@@ -306,17 +342,19 @@ extern "C" int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, co
   memset(&g, 0, sizeof(g));
   geom_in(g, x);
   geom_out(g, y);
-  g.Qz = y->z, g.Qy = y->y, g.Qx = y->x, g.Vq = (int)rx_act_voxels(y);
+  g.nph = 1;
+  IgemmPhase& P = g.ph[0];
+  P.Qz = y->z, P.Qy = y->y, P.Qx = y->x, P.Vq = (int)rx_act_voxels(y);
   g.isz = stride[0], g.isy = stride[1], g.isx = stride[2];
   g.osz = g.osy = g.osx = 1;
   const int pz = (kernel[0] - 1) / 2, py = (kernel[1] - 1) / 2, px = (kernel[2] - 1) / 2;
   for (int a = 0; a < kernel[0]; ++a)
     for (int b = 0; b < kernel[1]; ++b)
       for (int c = 0; c < kernel[2]; ++c) {
-        RxTap& t = g.taps[g.ntaps];
+        RxTap& t = g.taps[P.ntaps];
         t.dz = (int8_t)(a - pz), t.dy = (int8_t)(b - py), t.dx = (int8_t)(c - px);
-        t.w = (uint8_t)g.ntaps;
-        ++g.ntaps;
+        t.w = (uint8_t)P.ntaps;
+        ++P.ntaps;
       }
   return igemm_launch(dt, x->ptr, w_fwd, bias, y->ptr, g, x->n, ws, wsb, (hipStream_t)stream);
 }
@@ -337,41 +375,43 @@ extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_b
   const int k[3] = {kernel[0], kernel[1], kernel[2]}, s[3] = {stride[0], stride[1], stride[2]};
   const int p[3] = {(k[0] - 1) / 2, (k[1] - 1) / 2, (k[2] - 1) / 2};
   const int din[3] = {dx->z, dx->y, dx->x};
-  // dx[s*q + r] = sum_{t : (r+p-t) % s == 0} dy[q + (r+p-t)/s] * W[t]^T      per axis
+  // dx[s*q + r] = sum_{t : (r+p-t) % s == 0} dy[q + (r+p-t)/s] * W[t]^T      per axis; one PHASE per parity class r
+  IgemmGeom g;
+  memset(&g, 0, sizeof(g));
+  geom_in(g, dy);
+  geom_out(g, dx);
+  g.isz = g.isy = g.isx = 1;
+  g.osz = s[0], g.osy = s[1], g.osx = s[2];
+  g.accumulate = accumulate;
+  int ntap_total = 0;
   for (int r0 = 0; r0 < s[0]; ++r0)
     for (int r1 = 0; r1 < s[1]; ++r1)
       for (int r2 = 0; r2 < s[2]; ++r2) {
         const int r[3] = {r0, r1, r2};
-        IgemmGeom g;
-        memset(&g, 0, sizeof(g));
-        geom_in(g, dy);
-        geom_out(g, dx);
         int Q[3];
         for (int a = 0; a < 3; ++a) Q[a] = (din[a] - r[a] + s[a] - 1) / s[a];
-        g.Qz = Q[0], g.Qy = Q[1], g.Qx = Q[2], g.Vq = Q[0] * Q[1] * Q[2];
-        g.isz = g.isy = g.isx = 1;
-        g.osz = s[0], g.osy = s[1], g.osx = s[2];
-        g.opz = r0, g.opy = r1, g.opx = r2;
-        g.accumulate = accumulate;
+        if (Q[0] * Q[1] * Q[2] <= 0) continue;
+        IgemmPhase& P = g.ph[g.nph++];
+        P.Qz = Q[0], P.Qy = Q[1], P.Qx = Q[2], P.Vq = Q[0] * Q[1] * Q[2];
+        P.opz = r0, P.opy = r1, P.opx = r2;
+        P.tap0 = ntap_total;
         for (int a = 0; a < k[0]; ++a) {
           if ((r0 + p[0] - a) % s[0]) continue;
           for (int b = 0; b < k[1]; ++b) {
             if ((r1 + p[1] - b) % s[1]) continue;
             for (int c = 0; c < k[2]; ++c) {
               if ((r2 + p[2] - c) % s[2]) continue;
-              RxTap& t = g.taps[g.ntaps++];
+              RxTap& t = g.taps[ntap_total++];
               t.dz = (int8_t)((r0 + p[0] - a) / s[0]);
               t.dy = (int8_t)((r1 + p[1] - b) / s[1]);
               t.dx = (int8_t)((r2 + p[2] - c) / s[2]);
               t.w = (uint8_t)((a * k[1] + b) * k[2] + c);
+              ++P.ntaps;
             }
           }
         }
-        if (g.Vq <= 0) continue;
-        rc = igemm_launch(dt, dy->ptr, w_bwd, nullptr, dx->ptr, g, dx->n, ws, wsb, (hipStream_t)stream);
-        if (rc) return rc;
       }
-  return RX_OK;
+  return igemm_launch(dt, dy->ptr, w_bwd, nullptr, dx->ptr, g, dx->n, ws, wsb, (hipStream_t)stream);
 }
 
 static int checkT(const int32_t s[3], const rx_act* small, const rx_act* big, const char* who) {
@@ -387,25 +427,26 @@ extern "C" int rx_convT3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, c
   if (!rx_act_ok(x) || !rx_act_ok(y) || !w_fwd) RX_FAIL(RX_EINVAL, "rx_convT3d_fwd: bad arguments");
   int rc = checkT(stride, x, y, "rx_convT3d_fwd");
   if (rc) return rc;
-  // y[i*s + t] = sum_ci x[i] W[ci][co][t] + b : one single-tap GEMM per phase t
+  // y[i*s + t] = sum_ci x[i] W[ci][co][t] + b : one single-tap PHASE per kernel position t, one launch
+  IgemmGeom g;
+  memset(&g, 0, sizeof(g));
+  geom_in(g, x);
+  geom_out(g, y);
+  g.isz = g.isy = g.isx = 1;
+  g.osz = stride[0], g.osy = stride[1], g.osx = stride[2];
   for (int a = 0; a < stride[0]; ++a)
     for (int b = 0; b < stride[1]; ++b)
       for (int c = 0; c < stride[2]; ++c) {
-        IgemmGeom g;
-        memset(&g, 0, sizeof(g));
-        geom_in(g, x);
-        geom_out(g, y);
-        g.Qz = x->z, g.Qy = x->y, g.Qx = x->x, g.Vq = (int)rx_act_voxels(x);
-        g.isz = g.isy = g.isx = 1;
-        g.osz = stride[0], g.osy = stride[1], g.osx = stride[2];
-        g.opz = a, g.opy = b, g.opx = c;
-        g.ntaps = 1;
-        g.taps[0].dz = g.taps[0].dy = g.taps[0].dx = 0;
-        g.taps[0].w = (uint8_t)((a * stride[1] + b) * stride[2] + c);
-        rc = igemm_launch(dt, x->ptr, w_fwd, bias, y->ptr, g, x->n, ws, wsb, (hipStream_t)stream);
-        if (rc) return rc;
+        IgemmPhase& P = g.ph[g.nph];
+        P.Qz = x->z, P.Qy = x->y, P.Qx = x->x, P.Vq = (int)rx_act_voxels(x);
+        P.opz = a, P.opy = b, P.opx = c;
+        P.tap0 = g.nph, P.ntaps = 1;
+        RxTap& t = g.taps[g.nph];
+        t.dz = t.dy = t.dx = 0;
+        t.w = (uint8_t)((a * stride[1] + b) * stride[2] + c);
+        ++g.nph;
       }
-  return RX_OK;
+  return igemm_launch(dt, x->ptr, w_fwd, bias, y->ptr, g, x->n, ws, wsb, (hipStream_t)stream);
 }
 
 extern "C" int rx_convT3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx, const int32_t stride[3],
@@ -418,17 +459,19 @@ extern "C" int rx_convT3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_
   memset(&g, 0, sizeof(g));
   geom_in(g, dy);
   geom_out(g, dx);
-  g.Qz = dx->z, g.Qy = dx->y, g.Qx = dx->x, g.Vq = (int)rx_act_voxels(dx);
+  g.nph = 1;
+  IgemmPhase& P = g.ph[0];
+  P.Qz = dx->z, P.Qy = dx->y, P.Qx = dx->x, P.Vq = (int)rx_act_voxels(dx);
   g.isz = stride[0], g.isy = stride[1], g.isx = stride[2];
   g.osz = g.osy = g.osx = 1;
   g.accumulate = accumulate;
   for (int a = 0; a < stride[0]; ++a)
     for (int b = 0; b < stride[1]; ++b)
       for (int c = 0; c < stride[2]; ++c) {
-        RxTap& t = g.taps[g.ntaps];
+        RxTap& t = g.taps[P.ntaps];
         t.dz = (int8_t)a, t.dy = (int8_t)b, t.dx = (int8_t)c;
-        t.w = (uint8_t)g.ntaps;
-        ++g.ntaps;
+        t.w = (uint8_t)P.ntaps;
+        ++P.ntaps;
       }
   return igemm_launch(dt, dy->ptr, w_bwd, nullptr, dx->ptr, g, dx->n, ws, wsb, (hipStream_t)stream);
 }

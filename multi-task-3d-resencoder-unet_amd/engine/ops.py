@@ -184,9 +184,7 @@ def conv3d_bwd_data(dy, w_bwd, dx, kernel, stride, accumulate=False, ws=None):
     if _PROF is None:
         return go()
     n = dy.dims[0]
-    classes = stride[0] * stride[1] * stride[2]
-    name = "dgrad:" + (LaunchProfiler.igemm_name(dx.voxels, dx.c) if classes == 1 else "igemm_kernel<strided classes>")
-    _PROF.run(name, 2.0 * n * dy.voxels * dy.c * dx.c * _taps(kernel), classes, go)
+    _PROF.run("dgrad:" + LaunchProfiler.igemm_name(dx.voxels, dx.c), 2.0 * n * dy.voxels * dy.c * dx.c * _taps(kernel), 1, go)
 
 
 def conv3d_bwd_weight(x, dy, dw, kernel, stride, ws=None):
