@@ -437,8 +437,9 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
     }
     g.dbg = dbg;
   }
-  const int BN = (g.Co % 64 == 0) ? 64 : 32;
-  if ((long)g.NT * (g.Co / BN) < 192) return 0;  // too few workgroups: the split-K gather kernel fills the chip better
+  int BN = (g.Co % 64 == 0) ? 64 : 32;
+  if (BN == 64 && (long)g.NT * (g.Co / 64) < 256) BN = 32;  // under-filled grid: twice the workgroups, half the work each
+  if ((long)g.NT * (g.Co / BN) < 128) return 0;  // too few workgroups: the split-K gather kernel fills the chip better
   dim3 grid(g.NT, g.Co / BN);
   if (BN == 32 && TZ == 4 && TY == 4 && TX == 16) {  // full-resolution layers: compile-time tile, padded rows
     rx_note_kernel("conv_halo32_kernel");

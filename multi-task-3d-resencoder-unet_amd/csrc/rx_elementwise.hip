@@ -925,16 +925,18 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   }
 }
 
-__global__ void stem_wgrad_finalize(const float* __restrict__ partial, int nch, int Cin, int ky, int kx, int TT, int Co,
-                                    float* __restrict__ dw) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;  // over (co, ci, t) torch layout
+__global__ __launch_bounds__(256) void stem_wgrad_finalize(const float* __restrict__ partial, int nch, int Cin, int ky, int kx, int TT, int Co,
+                                                           float* __restrict__ dw) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per (co, ci, t) of the torch layout
   if (i >= Co * Cin * TT) return;
   int co = i / (Cin * TT), r = i - co * (Cin * TT), ci = r / TT, t = r - ci * TT;
   int a = t / (ky * kx), b = (t / kx) % ky, c = t % kx;
   int slot = a * 9 + b * 3 + c;
   double s = 0.0;
-  for (int k = 0; k < nch; ++k) s += (double)partial[(((size_t)k * Cin + ci) * 27 + slot) * Co + co];
-  dw[i] = (float)s;
+  for (int k = lane; k < nch; k += 64) s += (double)partial[(((size_t)k * Cin + ci) * 27 + slot) * Co + co];
+  s = wave_sum_d(s);
+  if (lane == 0) dw[i] = (float)s;
 }
 
 int rx_stem_wgrad_mfma_try(rx_dtype dt, const float* x, int n, int cin, int z, int y, int xx, const rx_act* dy, const int32_t kernel[3],
@@ -961,7 +963,7 @@ extern "C" int rx_stem_conv_bwd_weight(rx_dtype dt, const float* x_ncdhw, int n,
     if (rx_stem_wgrad_mfma_try(dt, x_ncdhw, n, cin, z, y, x, dy, kernel, (float*)ws, RX_STEM_CHUNKS, &nb, st0) == 1) {
       const int TT0 = kernel[0] * kernel[1] * kernel[2];
       int tot0 = Co * cin * TT0;
-      hipLaunchKernelGGL(stem_wgrad_finalize, dim3((tot0 + 255) / 256), dim3(256), 0, st0, (const float*)ws, nb, cin, kernel[1], kernel[2],
+      hipLaunchKernelGGL(stem_wgrad_finalize, dim3((tot0 + 3) / 4), dim3(256), 0, st0, (const float*)ws, nb, cin, kernel[1], kernel[2],
                          TT0, Co, dw);
       RX_CHECK_LAUNCH("rx_stem_conv_bwd_weight(mfma)");
       return RX_OK;
@@ -978,7 +980,7 @@ extern "C" int rx_stem_conv_bwd_weight(rx_dtype dt, const float* x_ncdhw, int n,
     hipLaunchKernelGGL((stem_wgrad_kernel<T>), dim3(nch, 1, cin), dim3(256), 0, st, x_ncdhw, cin, z, y, x, (const T*)dy->ptr, dy->ld,
                        rx_act_voxels(dy) * dy->ld, Co, kernel[0], kernel[1], kernel[2], n, (int)chunk, (float*)ws);
     int tot = Co * cin * TT;
-    hipLaunchKernelGGL(stem_wgrad_finalize, dim3((tot + 255) / 256), dim3(256), 0, st, (const float*)ws, nch, cin, kernel[1], kernel[2], TT, Co,
+    hipLaunchKernelGGL(stem_wgrad_finalize, dim3((tot + 3) / 4), dim3(256), 0, st, (const float*)ws, nch, cin, kernel[1], kernel[2], TT, Co,
                        dw);
   });
   RX_CHECK_LAUNCH("rx_stem_conv_bwd_weight");

@@ -101,6 +101,10 @@ class Plan:
         self._grads: List[Optional[torch.Tensor]] = []
         self.grad_order: List[int] = []       # parameter indices in the order their gradients become ready
         self.grad_sync = None                 # optional engine.ddp.GradSync
+        self.overlap_wgrad = True             # weight gradients on a side HIP stream (off the dependency chain)
+        self._side = None
+        self._ws2 = None
+        self._dy_turn: Dict[tuple, int] = {}
         self._build()
 
     # ------------------------------------------------------------------ helpers
@@ -346,12 +350,17 @@ class Plan:
                     f.append(step)
 
     def _dy_for(self, y: AT):
+        """scratch buffer for dL/dy of a conv output.  Two per shape, used alternately: the weight-gradient kernel
+        of layer L (side stream) may still be reading its dy while layer L-1's backward already writes the next."""
         key = (y.act.dims, y.act.c)
-        if key not in self.dy_pool:
+        turn = self._dy_turn.get(key, 0)
+        self._dy_turn[key] = turn ^ 1
+        slot = key + (turn,)
+        if slot not in self.dy_pool:
             t = torch.empty((*y.act.dims, y.act.c), dtype=self.dtype, device=self.device)
             self.bytes_alloc += t.numel() * t.element_size()
-            self.dy_pool[key] = Act(t)
-        return self.dy_pool[key]
+            self.dy_pool[slot] = Act(t)
+        return self.dy_pool[slot]
 
     def _gen_backward(self):
         P = self
@@ -376,6 +385,30 @@ class Plan:
         def done(idx):
             if P.grad_sync is not None:
                 P.grad_sync.ready(idx)
+
+        # events guarding the two dy slots of every shape: the side stream's last reader of a slot must be done
+        # before the main stream writes that slot again
+        dy_free = {}
+
+        def side_run(fn, dy_act):
+            """run `fn` (weight-gradient launches reading dy_act) on the side stream, ordered after everything the
+            main stream has enqueued so far"""
+            if not (P.overlap_wgrad and P._side is not None):
+                fn(ops.workspace())
+                return
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            P._side.wait_event(ev)
+            with torch.cuda.stream(P._side):
+                fn(P._ws2)
+                fin = torch.cuda.Event()
+                fin.record(P._side)
+            dy_free[id(dy_act.t)] = fin
+
+        def before_dy_write(dy_act):
+            ev = dy_free.pop(id(dy_act.t), None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
 
         order = self.grad_order
 
@@ -415,23 +448,29 @@ class Plan:
                         gres = self._grad_buf(res)
                         acc = view_written(res)
                         res.written = True
-                    b.append(lambda a=a, gout=gout, dy=dy, gres=gres, acc=acc: ops.instnorm_act_bwd(
-                        gout, a["y"].act, a["stats"], a["out"].act if a["slope"] != 1.0 else None, dy, a["slope"],
-                        gres, acc))
+                    def istep(a=a, gout=gout, dy=dy, gres=gres, acc=acc):
+                        before_dy_write(dy)
+                        ops.instnorm_act_bwd(gout, a["y"].act, a["stats"], a["out"].act if a["slope"] != 1.0 else None, dy,
+                                             a["slope"], gres, acc)
+                    b.append(istep)
                 elif rec.kind in ("conv", "stem"):
                     y = a["y"]
                     dy = y.gact
 
                     def wstep(a=a, dy=dy, kind=rec.kind):
                         dw = new_grad(a["widx"])
-                        if kind == "stem":
-                            ops.stem_conv_bwd_weight(P._x, dy, dw, a["kernel"])
-                        else:
-                            ops.conv3d_bwd_weight(a["x"].act, dy, dw, a["kernel"], a["stride"])
-                        done(a["widx"])
-                        if a["bidx"] is not None:
-                            ops.channel_sum(dy, new_grad(a["bidx"]))
-                            done(a["bidx"])
+                        db = new_grad(a["bidx"]) if a["bidx"] is not None else None
+
+                        def launches(ws):
+                            if kind == "stem":
+                                ops.stem_conv_bwd_weight(P._x, dy, dw, a["kernel"], ws)
+                            else:
+                                ops.conv3d_bwd_weight(a["x"].act, dy, dw, a["kernel"], a["stride"], ws)
+                            done(a["widx"])
+                            if db is not None:
+                                ops.channel_sum(dy, db, ws)
+                                done(a["bidx"])
+                        side_run(launches, dy)
                     order += [a["widx"]] + ([a["bidx"]] if a["bidx"] is not None else [])
                     b.append(wstep)
                     if rec.kind == "conv":
@@ -454,11 +493,15 @@ class Plan:
 
                     def step(a=a, gy=gy, gx=gx, acc=acc):
                         dw = new_grad(a["widx"])
-                        ops.convT3d_bwd_weight(a["x"].act, gy, dw, a["stride"])
-                        done(a["widx"])
-                        if a["bidx"] is not None:
-                            ops.channel_sum(gy, new_grad(a["bidx"]))
-                            done(a["bidx"])
+                        db = new_grad(a["bidx"]) if a["bidx"] is not None else None
+
+                        def launches(ws):
+                            ops.convT3d_bwd_weight(a["x"].act, gy, dw, a["stride"], ws)
+                            done(a["widx"])
+                            if db is not None:
+                                ops.channel_sum(gy, db, ws)
+                                done(a["bidx"])
+                        side_run(launches, gy)      # gy is a gradient buffer that is not rewritten in this backward
                         ops.convT3d_bwd_data(gy, a["pk"]["w_bwd"], gx, a["stride"], acc)
                     order += [a["widx"]] + ([a["bidx"]] if a["bidx"] is not None else [])
                     b.append(step)
@@ -534,10 +577,15 @@ class Plan:
                 g = g.float().contiguous()
             self._dlogits[k] = g.unsqueeze(2) if self.two_d else g
         self._grads = [None] * len(self.params)
+        if self.overlap_wgrad and self._side is None and self.device.type == "cuda":
+            self._side = torch.cuda.Stream(device=self.device)
+            self._ws2 = torch.empty(ops.workspace().numel(), dtype=torch.uint8, device=self.device)
         if self.grad_sync is not None:
             self.grad_sync.begin(self)
         for step in self.bwd:
             step()
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)     # every weight gradient is complete
         if self.grad_sync is not None:
             self.grad_sync.finish()
         grads = self._grads
