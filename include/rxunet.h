@@ -94,7 +94,8 @@ int rx_instnorm_stats(rx_dtype dt, const rx_act* y, float eps, float* stats, voi
 /* out = lrelu_slope( (y-mean)*rstd + residual ); residual may be NULL; slope = 1 -> no activation */
 int rx_instnorm_act_fwd(rx_dtype dt, const rx_act* y, const float* stats, const rx_act* residual,
                         const rx_act* out, float slope, void* stream);
-/* g = dL/dout; `out` supplies the sign for the LeakyReLU mask (NULL when slope == 1).
+/* g = dL/dout; `out` supplies the sign for the LeakyReLU mask.  out == NULL with slope != 1 means "no residual was
+ * added": the mask is then the sign of the normalised value and the output tensor is not read.
  * dy = dL/dy; d_residual (optional) receives (or accumulates) g*mask.  ws as for stats. */
 int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out,
                         float slope, const rx_act* dy, const rx_act* d_residual, int accumulate_residual,

@@ -365,7 +365,8 @@ struct InBwdOp {
   const float* stats;
   int C;
   float slope;
-  bool use_mask;
+  bool use_mask;   // LeakyReLU mask from the sign of the saved output (residual blocks)
+  bool mask_xhat;  // no residual: out > 0 <=> xhat > 0, the output tensor is not read at all
   float mean[Elem<T>::PER16], rstd[Elem<T>::PER16];
   __device__ inline void prepare(int n, int c0) {
 #pragma unroll
@@ -383,8 +384,9 @@ struct InBwdOp {
 #pragma unroll
     for (int j = 0; j < P; ++j) {
       float gg = Elem<T>::to_f(gv.v[j]);
-      if (use_mask && !(Elem<T>::to_f(ov.v[j]) > 0.f)) gg *= slope;
       float xh = (Elem<T>::to_f(yv.v[j]) - mean[j]) * rstd[j];
+      if (use_mask && !(Elem<T>::to_f(ov.v[j]) > 0.f)) gg *= slope;
+      if (mask_xhat && !(xh > 0.f)) gg *= slope;
       acc[0][j] += gg;
       acc[1][j] += gg * xh;
     }
@@ -418,14 +420,15 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restri
     Vec16<T> gv = ld16(g + n * sg + v * ldg + cv * P);
     Vec16<T> yv = ld16(y + n * sy + v * ldy + cv * P);
     Vec16<T> ov;
-    if (use_mask) ov = ld16(out + n * so + v * ldo + cv * P);
+    if (use_mask == 1) ov = ld16(out + n * so + v * ldo + cv * P);
     Vec16<T> dv, rv;
     if (HAS_DRES && ACC_DRES) rv = ld16(dres + n * sdr + v * lddr + cv * P);
 #pragma unroll
     for (int j = 0; j < P; ++j) {
       float gg = Elem<T>::to_f(gv.v[j]);
-      if (use_mask && !(Elem<T>::to_f(ov.v[j]) > 0.f)) gg *= slope;
       float xh = (Elem<T>::to_f(yv.v[j]) - mean[j]) * rstd[j];
+      if (use_mask == 1 && !(Elem<T>::to_f(ov.v[j]) > 0.f)) gg *= slope;
+      if (use_mask == 2 && !(xh > 0.f)) gg *= slope;
       dv.v[j] = Elem<T>::from_f(rstd[j] * (gg - m1[j] - xh * m2[j]));
       if (HAS_DRES) {
         float r = gg;
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restri
   hipLaunchKernelGGL((in_act_bwd_apply_kernel<T, HD, AD>), dim3(G, N), dim3(256), 0, st, (const T*)g->ptr, g->ld, V * g->ld,     \
                      (const T*)y->ptr, y->ld, V * y->ld, outp, ldo, V * ldo, stats, (const float*)m12, (T*)dy->ptr, dy->ld,       \
                      V * dy->ld, d_residual ? (T*)d_residual->ptr : (T*)nullptr, d_residual ? d_residual->ld : 0,                 \
-                     d_residual ? V * d_residual->ld : 0L, (int)V, C, slope, (int)use_mask)
+                     d_residual ? V * d_residual->ld : 0L, (int)V, C, slope, use_mask ? 1 : (mask_xhat ? 2 : 0))
 
 extern "C" int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out,
                                    float slope, const rx_act* dy, const rx_act* d_residual, int accumulate_residual, void* ws,
@@ -451,9 +454,10 @@ extern "C" int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y
   if ((rc = check_vec_channels(g, dt, "rx_instnorm_act_bwd(g)"))) return rc;
   if ((rc = check_vec_channels(y, dt, "rx_instnorm_act_bwd(y)"))) return rc;
   if ((rc = check_vec_channels(dy, dt, "rx_instnorm_act_bwd(dy)"))) return rc;
-  const bool use_mask = slope != 1.0f;
+  // mask source: none (slope 1) | sign of xhat (no residual: `out` may be NULL and is never read) | saved output
+  const bool mask_xhat = slope != 1.0f && out == nullptr;
+  const bool use_mask = slope != 1.0f && out != nullptr;
   if (use_mask) {
-    if (!out) RX_FAIL(RX_EINVAL, "rx_instnorm_act_bwd: `out` is required when slope != 1");
     if ((rc = check_vec_channels(out, dt, "rx_instnorm_act_bwd(out)"))) return rc;
     if (!same_geom(y, out)) RX_FAIL(RX_EINVAL, "rx_instnorm_act_bwd: out geometry mismatch");
   }
@@ -473,7 +477,7 @@ extern "C" int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y
     constexpr int P = Elem<T>::PER16;
     ReducePlan p = rx_reduce_plan(V, C, P);
     int CV = C / P, VP = 256 / CV;
-    InBwdOp<T> op{make_view<T>(g), make_view<T>(y), use_mask ? make_view<T>(out) : make_view<T>(y), stats, C, slope, use_mask, {}, {}};
+    InBwdOp<T> op{make_view<T>(g), make_view<T>(y), use_mask ? make_view<T>(out) : make_view<T>(y), stats, C, slope, use_mask, mask_xhat, {}, {}};
     size_t lds = (size_t)2 * (VP > 4 ? VP : 4) * C * sizeof(float);
     hipLaunchKernelGGL((colreduce_kernel<T, 2, InBwdOp<T>>), dim3(p.nchunks, N), dim3(256), lds, st, op, (int)V, C, p.chunk_vox,
                        partial);

@@ -450,7 +450,9 @@ class Plan:
                         res.written = True
                     def istep(a=a, gout=gout, dy=dy, gres=gres, acc=acc):
                         before_dy_write(dy)
-                        ops.instnorm_act_bwd(gout, a["y"].act, a["stats"], a["out"].act if a["slope"] != 1.0 else None, dy,
+                        # the saved output is only needed for the mask of residual blocks (sign(out) != sign(xhat) there)
+                        ops.instnorm_act_bwd(gout, a["y"].act, a["stats"],
+                                             a["out"].act if (a["slope"] != 1.0 and a["res"] is not None) else None, dy,
                                              a["slope"], gres, acc)
                     b.append(istep)
                 elif rec.kind in ("conv", "stem"):

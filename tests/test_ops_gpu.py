@@ -162,6 +162,11 @@ def test_instnorm_lrelu_residual(ops, dtype, c, dims):
         dra = ops.Act.zeros(n, *dims, c, dtype) if with_res else None
         ops.instnorm_act_bwd(ga, ya, stats, out_ref_act if slope != 1.0 else None, dya, slope, dra, False)
         assert rel(dya.to_ncdhw(), yr.grad) < 3 * TOL[dtype]
+        if not with_res and slope != 1.0:
+            # no residual: the mask is the sign of the normalised value, the saved output is not needed at all
+            dyb = ops.Act.zeros(n, *dims, c, dtype)
+            ops.instnorm_act_bwd(ga, ya, stats, None, dyb, slope, None, False)
+            assert rel(dyb.to_ncdhw(), yr.grad) < 3 * TOL[dtype]
         if with_res:
             assert rel(dra.to_ncdhw(), rr.grad) < TOL[dtype]
             ops.instnorm_act_bwd(ga, ya, stats, out_ref_act, dya, slope, dra, True)   # accumulate
