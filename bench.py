@@ -229,6 +229,20 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ops.set_profiler(None)
+    # extra, outside the timed region: the same kernels WITHOUT stream overlap (weight gradients back on the main
+    # stream) so that per-kernel durations are free of the contention the overlapped schedule creates on purpose
+    iso = None
+    if prof is not None:
+        iso = ops.LaunchProfiler()
+        for plan in net._plans.values():
+            plan.overlap_wgrad = False
+        step()
+        ops.set_profiler(iso)
+        for _ in range(2):
+            step()
+        ops.set_profiler(None)
+        for plan in net._plans.values():
+            plan.overlap_wgrad = True
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -265,8 +279,20 @@ def main():
                        "global_batch": world * batch, "parallelism": f"dp{world}"},
             "final_loss": final_loss,
             "roofline": roofline,
+            "roofline_isolated": None,
             "kernels": kernels,
         }
+        if iso is not None:
+            gi = iso.collect()
+            if gi:
+                isolated = {k: dict(avg_us_per_launch=v["ms"] * 1e3 / max(v["launches"], 1), tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12)
+                            for k, v in gi.items() if v["ms"] > 0}
+                dom_i = roofline["kernel"] if roofline and roofline["kernel"] in isolated else max(isolated, key=lambda k: gi[k]["ms"])
+                line["roofline_isolated"] = dict(kernel=dom_i, achieved=isolated[dom_i]["tflops"], peak=peak, unit="TFLOP/s",
+                                                 frac=isolated[dom_i]["tflops"] / peak,
+                                                 avg_us_per_launch=isolated[dom_i]["avg_us_per_launch"],
+                                                 note="same kernels, weight-gradient stream overlap disabled (2 extra steps)",
+                                                 all=isolated)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
         else:

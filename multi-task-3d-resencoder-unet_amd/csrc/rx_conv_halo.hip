@@ -296,34 +296,26 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict
     const int dzoff = sgn * ((ph % 3) - 1) * (HY * HX * ROWB);  // wave-uniform byte offset of this dz plane
     const unsigned char* x0p = xb[0] + dzoff;
     const unsigned char* x1p = xb[1] + dzoff;
-    if (g.dbg & 4) {
-    } else if (sgn > 0) {
+    if (!(g.dbg & 4)) {
+      // 18 steps (9 taps x 2 k-steps), software pipelined by hand: the three fragment reads of step i+1 are issued
+      // before the two MFMAs of step i; sched_group_barrier pins the 2-MFMA / 3-DS_READ interleave.
+      const int ssg = sgn;
+      u32x4 fa[2], f0[2], f1[2];
+      auto ld = [&](int i, int slot) {
+        const int tl = i >> 1, ks = i & 1;
+        const int toff = ssg * ((tl / 3 - 1) * HX + (tl % 3 - 1)) * ROWB;
+        fa[slot] = *reinterpret_cast<const u32x4*>((ks ? wb1 : wb0) + tl * 32 * 64);
+        f0[slot] = *reinterpret_cast<const u32x4*>(x0p + toff + ks * 32);
+        f1[slot] = *reinterpret_cast<const u32x4*>(x1p + toff + ks * 32);
+      };
+      ld(0, 0);
 #pragma unroll
-      for (int tl = 0; tl < 9; ++tl) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int toff = ((tl / 3 - 1) * HX + (tl % 3 - 1)) * ROWB;  // compile-time after unrolling
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const u32x4 a = *reinterpret_cast<const u32x4*>((ks ? wb1 : wb0) + tl * 32 * 64);
-          const u32x4 b0 = *reinterpret_cast<const u32x4*>(x0p + toff + ks * 32);
-          const u32x4 b1 = *reinterpret_cast<const u32x4*>(x1p + toff + ks * 32);
-          Mma<T>::run(acc[0], a, b0);
-          Mma<T>::run(acc[1], a, b1);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int tl = 0; tl < 9; ++tl) {
-        const int toff = -((tl / 3 - 1) * HX + (tl % 3 - 1)) * ROWB;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const u32x4 a = *reinterpret_cast<const u32x4*>((ks ? wb1 : wb0) + tl * 32 * 64);
-          const u32x4 b0 = *reinterpret_cast<const u32x4*>(x0p + toff + ks * 32);
-          const u32x4 b1 = *reinterpret_cast<const u32x4*>(x1p + toff + ks * 32);
-          Mma<T>::run(acc[0], a, b0);
-          Mma<T>::run(acc[1], a, b1);
-        }
+      for (int i = 0; i < 18; ++i) {
+        if (i + 1 < 18) ld(i + 1, (i + 1) & 1);
+        Mma<T>::run(acc[0], fa[i & 1], f0[i & 1]);
+        Mma<T>::run(acc[1], fa[i & 1], f1[i & 1]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // 3 DS reads (next step)
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMAs (this step)
       }
     }
   }
