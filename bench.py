@@ -36,6 +36,14 @@ WORKLOADS = {
                  tasks={"sheet": {"channels": 1, "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss",
                                   "loss_kwargs": {"alpha": 0.5, "beta": 0.5}},
                         "normals": {"channels": 3, "activation": "none", "weight": 1, "loss_fn": "MaskedCosineLoss"}}),
+    # configs[4]: manual 6-stage topology capped at 320 features, 2 input channels, 160^3 (run it with --dtype fp16)
+    "cfg5": dict(patch=(160, 160, 160), in_channels=2, batch=1, autoconfigure=False,
+                 model_config={"basic_encoder_block": "BasicBlockD", "basic_decoder_block": "ConvBlock",
+                               "bottleneck_block": "BasicBlockD", "features_per_stage": [32, 64, 128, 256, 320, 320],
+                               "num_stages": 6, "n_blocks_per_stage": [1, 3, 4, 6, 6, 6], "kernel_sizes": [3] * 6,
+                               "n_conv_per_stage_decoder": [1] * 5, "strides": [1, 2, 2, 2, 2, 2]},
+                 tasks={"sheet": {"channels": 1, "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss",
+                                  "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}),
     # configs[0]: 64^3 plumbing case
     "cfg1": dict(patch=(64, 64, 64), in_channels=1, batch=2, autoconfigure=True, model_config={},
                  tasks={"sheet": {"channels": 1, "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss",
@@ -273,8 +281,9 @@ def main():
             "metric": "train patches/sec (b,c,z,y,x) ResEncM 1x128^3", "value": value, "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.workload}: autoconfigured ResEncM (6 stages, feats 32..512, blocks 1/3/4/6/6/6), "
-                                   f"1-in, heads {list(w['tasks'])}, patch {'x'.join(map(str, w['patch']))}, "
+            "config": {"workload": f"{args.workload}: ResEncM ({net.num_stages} stages, feats {list(net.features_per_stage)}, "
+                                   f"blocks {list(net.n_blocks_per_stage)}), "
+                                   f"{w['in_channels']}-in, heads {list(w['tasks'])}, patch {'x'.join(map(str, w['patch']))}, "
                                    f"batch {batch}/GPU, full train step (fwd+loss+bwd+allreduce+clip+AdamW)",
                        "global_batch": world * batch, "parallelism": f"dp{world}"},
             "final_loss": final_loss,
