@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)   # "gloo": rehearse N>1 on a 1-GPU box
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -175,10 +176,14 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     import mt3d_amd  # noqa: F401
     from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
