@@ -94,6 +94,10 @@ int rx_instnorm_stats(rx_dtype dt, const rx_act* y, float eps, float* stats, voi
 /* out = lrelu_slope( (y-mean)*rstd + residual ); residual may be NULL; slope = 1 -> no activation */
 int rx_instnorm_act_fwd(rx_dtype dt, const rx_act* y, const float* stats, const rx_act* residual,
                         const rx_act* out, float slope, void* stream);
+/* stats + apply in one call: one launch when the tensor is small (<= 8^3 voxels per sample, C % 32 == 0), otherwise the two
+ * calls above.  Writes stats (kept for the backward). */
+int rx_instnorm_fwd(rx_dtype dt, const rx_act* y, float eps, float* stats, const rx_act* residual,
+                    const rx_act* out, float slope, void* ws, size_t ws_bytes, void* stream);
 /* g = dL/dout; `out` supplies the sign for the LeakyReLU mask.  out == NULL with slope != 1 means "no residual was
  * added": the mask is then the sign of the normalised value and the output tensor is not read.
  * dy = dL/dy; d_residual (optional) receives (or accumulates) g*mask.  ws as for stats. */

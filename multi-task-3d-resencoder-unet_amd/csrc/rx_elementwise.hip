@@ -8,6 +8,7 @@
 #include <stdarg.h>
 
 #include "rx_common.h"
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------
 // error string
@@ -447,6 +448,186 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restri
                      V * dy->ld, d_residual ? (T*)d_residual->ptr : (T*)nullptr, d_residual ? d_residual->ld : 0,                 \
                      d_residual ? V * d_residual->ld : 0L, (int)V, C, slope, use_mask ? 1 : (mask_xhat ? 2 : 0))
 
+// ---- single-launch InstanceNorm forward / backward for SMALL tensors (low-resolution stages) ---------------------
+// At 8^3 and below (measured: 16^3 is already better off with the chip-filling three-launch path; narrower 8-channel
+// groups did not change that) a layer's tensor is a few hundred KB and the three launches (partials, finalize, apply) are pure
+// launch latency on the critical chain.  One workgroup owns (sample n, 32 consecutive channels): pass 1 reduces over all
+// voxels (thread = (voxel lane, 16-byte channel chunk); xor-shuffle across the 16 voxel lanes of a wave, LDS across the
+// 4 waves, fp64 for the final combination), pass 2 re-reads the (L2-resident) data and applies.
+template <typename T, int G, bool HAS_RES>
+__global__ __launch_bounds__(256) void in_small_fwd_kernel(const T* __restrict__ y, int ldy, long sy, const T* __restrict__ res, int ldr,
+                                                           long sr, T* __restrict__ out, int ldo, long so, float* __restrict__ stats, int V,
+                                                           int C, float eps, float slope) {
+  constexpr int P = Elem<T>::PER16;
+  constexpr int CPG = G / P;  // 16-byte chunks per G-channel group
+  __shared__ double red[4][2][G];
+  __shared__ float mr[2][G];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.y, c0 = blockIdx.x * G;
+  const int ck = tid % CPG, vl = tid / CPG;
+  const int VL = 256 / CPG;
+  const T* yn = y + n * sy + c0 + ck * P;
+  float s[P], q[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) s[j] = q[j] = 0.f;
+  for (int v = vl; v < V; v += VL) {
+    Vec16<T> a = ld16(yn + (long)v * ldy);
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      float f = Elem<T>::to_f(a.v[j]);
+      s[j] += f;
+      q[j] += f * f;
+    }
+  }
+  for (int o = CPG; o < 64; o <<= 1) {
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      s[j] += __shfl_xor(s[j], o, 64);
+      q[j] += __shfl_xor(q[j], o, 64);
+    }
+  }
+  if (lane < CPG) {
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      red[wave][0][lane * P + j] = (double)s[j];
+      red[wave][1][lane * P + j] = (double)q[j];
+    }
+  }
+  __syncthreads();
+  if (tid < G) {
+    double s0 = red[0][0][tid] + red[1][0][tid] + red[2][0][tid] + red[3][0][tid];
+    double s1 = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
+    double mean = s0 / V, var = s1 / V - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)eps));
+    mr[0][tid] = m;
+    mr[1][tid] = r;
+    stats[2 * ((size_t)n * C + c0 + tid)] = m;
+    stats[2 * ((size_t)n * C + c0 + tid) + 1] = r;
+  }
+  __syncthreads();
+  float mean[P], rstd[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    mean[j] = mr[0][ck * P + j];
+    rstd[j] = mr[1][ck * P + j];
+  }
+  const T* rn = HAS_RES ? res + n * sr + c0 + ck * P : nullptr;
+  T* on = out + n * so + c0 + ck * P;
+  for (int v = vl; v < V; v += VL) {
+    Vec16<T> a = ld16(yn + (long)v * ldy);
+    Vec16<T> r;
+    if (HAS_RES) r = ld16(rn + (long)v * ldr);
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      float f = (Elem<T>::to_f(a.v[j]) - mean[j]) * rstd[j];
+      if (HAS_RES) f += Elem<T>::to_f(r.v[j]);
+      f = f > 0.f ? f : f * slope;
+      o.v[j] = Elem<T>::from_f(f);
+    }
+    st16(on + (long)v * ldo, o);
+  }
+}
+
+// mask_mode: 0 none, 1 sign of `out`, 2 sign of xhat
+template <typename T, int G>
+__global__ __launch_bounds__(256) void in_small_bwd_kernel(const T* __restrict__ g, int ldg, long sg, const T* __restrict__ y, int ldy, long sy,
+                                                           const T* __restrict__ out, int ldo, long so, const float* __restrict__ stats,
+                                                           T* __restrict__ dy, int lddy, long sdy, T* __restrict__ dres, int lddr, long sdr,
+                                                           int acc_res, int V, int C, float slope, int mask_mode) {
+  constexpr int P = Elem<T>::PER16;
+  constexpr int CPG = G / P;
+  __shared__ double red[4][2][G];
+  __shared__ float mm[2][G];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.y, c0 = blockIdx.x * G;
+  const int ck = tid % CPG, vl = tid / CPG;
+  const int VL = 256 / CPG;
+  const long co = c0 + ck * P;
+  float mean[P], rstd[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    mean[j] = stats[2 * ((size_t)n * C + co + j)];
+    rstd[j] = stats[2 * ((size_t)n * C + co + j) + 1];
+  }
+  auto gprime = [&](int v, float (&gg)[P], float (&xh)[P]) {
+    Vec16<T> gv = ld16(g + n * sg + (long)v * ldg + co);
+    Vec16<T> yv = ld16(y + n * sy + (long)v * ldy + co);
+    Vec16<T> ov;
+    if (mask_mode == 1) ov = ld16(out + n * so + (long)v * ldo + co);
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      gg[j] = Elem<T>::to_f(gv.v[j]);
+      xh[j] = (Elem<T>::to_f(yv.v[j]) - mean[j]) * rstd[j];
+      if (mask_mode == 1 && !(Elem<T>::to_f(ov.v[j]) > 0.f)) gg[j] *= slope;
+      if (mask_mode == 2 && !(xh[j] > 0.f)) gg[j] *= slope;
+    }
+  };
+  float s[P], q[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) s[j] = q[j] = 0.f;
+  for (int v = vl; v < V; v += VL) {
+    float gg[P], xh[P];
+    gprime(v, gg, xh);
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      s[j] += gg[j];
+      q[j] += gg[j] * xh[j];
+    }
+  }
+  for (int o = CPG; o < 64; o <<= 1) {
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      s[j] += __shfl_xor(s[j], o, 64);
+      q[j] += __shfl_xor(q[j], o, 64);
+    }
+  }
+  if (lane < CPG) {
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      red[wave][0][lane * P + j] = (double)s[j];
+      red[wave][1][lane * P + j] = (double)q[j];
+    }
+  }
+  __syncthreads();
+  if (tid < G) {
+    mm[0][tid] = (float)((red[0][0][tid] + red[1][0][tid] + red[2][0][tid] + red[3][0][tid]) / V);
+    mm[1][tid] = (float)((red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid]) / V);
+  }
+  __syncthreads();
+  float m1[P], m2[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    m1[j] = mm[0][ck * P + j];
+    m2[j] = mm[1][ck * P + j];
+  }
+  for (int v = vl; v < V; v += VL) {
+    float gg[P], xh[P];
+    gprime(v, gg, xh);
+    Vec16<T> dv, rv;
+    if (dres && acc_res) rv = ld16(dres + n * sdr + (long)v * lddr + co);
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      dv.v[j] = Elem<T>::from_f(rstd[j] * (gg[j] - m1[j] - xh[j] * m2[j]));
+      if (dres) {
+        float r = gg[j];
+        if (acc_res) r += Elem<T>::to_f(rv.v[j]);
+        rv.v[j] = Elem<T>::from_f(r);
+      }
+    }
+    st16(dy + n * sdy + (long)v * lddy + co, dv);
+    if (dres) st16(dres + n * sdr + (long)v * lddr + co, rv);
+  }
+}
+
+// tuning knob (env RX_IN_SMALL_MAX, read once): largest per-sample voxel count that takes the single-launch path
+static long rx_in_small_max() {
+  static long v = [] { const char* e = getenv("RX_IN_SMALL_MAX"); return e ? atol(e) : 512L; }();
+  return v;
+}
+#define RX_IN_SMALL_MAX_VOXELS rx_in_small_max()
+
 extern "C" int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out,
                                    float slope, const rx_act* dy, const rx_act* d_residual, int accumulate_residual, void* ws,
                                    size_t ws_bytes, void* stream) {
@@ -468,6 +649,22 @@ extern "C" int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y
   if (!stats || !ws || !same_geom(y, g) || !same_geom(y, dy)) RX_FAIL(RX_EINVAL, "rx_instnorm_act_bwd: bad arguments");
   const long V = rx_act_voxels(y);
   const int N = y->n, C = y->c;
+  if (V <= RX_IN_SMALL_MAX_VOXELS && C % 32 == 0) {   // low-resolution stages: one launch instead of three
+    hipStream_t st1 = (hipStream_t)stream;
+    const int mode = use_mask ? 1 : (mask_xhat ? 2 : 0);
+    dim3 grid1(C / 32, N);
+#define RX_LAUNCH_IN_SMALL_BWD(G)                                                                                                     \
+  hipLaunchKernelGGL((in_small_bwd_kernel<T, G>), grid1, dim3(256), 0, st1, (const T*)g->ptr, g->ld, V * g->ld, (const T*)y->ptr, y->ld, \
+                     V * y->ld, use_mask ? (const T*)out->ptr : (const T*)nullptr, use_mask ? out->ld : 0,                           \
+                     use_mask ? V * out->ld : 0L, stats, (T*)dy->ptr, dy->ld, V * dy->ld,                                             \
+                     d_residual ? (T*)d_residual->ptr : (T*)nullptr, d_residual ? d_residual->ld : 0,                                 \
+                     d_residual ? V * d_residual->ld : 0L, accumulate_residual, (int)V, C, slope, mode)
+    RX_DISPATCH_DTYPE(dt, T, {
+      RX_LAUNCH_IN_SMALL_BWD(32);
+    });
+    RX_CHECK_LAUNCH("rx_instnorm_act_bwd(small)");
+    return RX_OK;
+  }
   size_t need = rx_reduce_ws_bytes(N, V, C, 2) + (size_t)N * C * 2 * sizeof(float);
   if (ws_bytes < need) RX_FAIL(RX_EWORKSPACE, "rx_instnorm_act_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
   float* partial = (float*)ws;
@@ -494,6 +691,38 @@ extern "C" int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y
       RX_LAUNCH_APPLY(true, false);
   });
   RX_CHECK_LAUNCH("rx_instnorm_act_bwd");
+  return RX_OK;
+}
+
+
+extern "C" int rx_instnorm_fwd(rx_dtype dt, const rx_act* y, float eps, float* stats, const rx_act* residual, const rx_act* out,
+                               float slope, void* ws, size_t ws_bytes, void* stream) {
+  int rc;
+  if ((rc = check_vec_channels(y, dt, "rx_instnorm_fwd(y)"))) return rc;
+  const long V = rx_act_voxels(y);
+  if (V > RX_IN_SMALL_MAX_VOXELS || y->c % 32) {   // large tensors: bandwidth-bound three-launch path
+    if ((rc = rx_instnorm_stats(dt, y, eps, stats, ws, ws_bytes, stream))) return rc;
+    return rx_instnorm_act_fwd(dt, y, stats, residual, out, slope, stream);
+  }
+  if ((rc = check_vec_channels(out, dt, "rx_instnorm_fwd(out)"))) return rc;
+  if (!stats || !same_geom(y, out)) RX_FAIL(RX_EINVAL, "rx_instnorm_fwd: geometry mismatch / null stats");
+  if (residual) {
+    if ((rc = check_vec_channels(residual, dt, "rx_instnorm_fwd(residual)"))) return rc;
+    if (!same_geom(y, residual)) RX_FAIL(RX_EINVAL, "rx_instnorm_fwd: residual geometry mismatch");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(y->c / 32, y->n);
+#define RX_LAUNCH_IN_SMALL_FWD(G, RES)                                                                                              \
+  hipLaunchKernelGGL((in_small_fwd_kernel<T, G, RES>), grid, dim3(256), 0, st, (const T*)y->ptr, y->ld, V * y->ld,                  \
+                     RES ? (const T*)residual->ptr : (const T*)nullptr, RES ? residual->ld : 0, RES ? V * residual->ld : 0L,         \
+                     (T*)out->ptr, out->ld, V * out->ld, stats, (int)V, y->c, eps, slope)
+  RX_DISPATCH_DTYPE(dt, T, {
+    if (residual)
+      RX_LAUNCH_IN_SMALL_FWD(32, true);
+    else
+      RX_LAUNCH_IN_SMALL_FWD(32, false);
+  });
+  RX_CHECK_LAUNCH("rx_instnorm_fwd");
   return RX_OK;
 }
 

@@ -233,6 +233,14 @@ def instnorm_act_fwd(y, stats, out, slope=0.01, residual=None):
                                      float(slope), stream_ptr()), "rx_instnorm_act_fwd")
 
 
+def instnorm_fwd(y, stats, out, slope=0.01, residual=None, eps=1e-5, ws=None):
+    """stats + apply; a single launch for the low-resolution stages."""
+    ws = workspace() if ws is None else ws
+    check(load().rx_instnorm_fwd(_code(y.dtype), byref(y.desc()), eps, _ptr(stats),
+                                 byref(residual.desc()) if residual is not None else None, byref(out.desc()),
+                                 float(slope), *_ws_args(ws), stream_ptr()), "rx_instnorm_fwd")
+
+
 def instnorm_act_bwd(g, y, stats, out, dy, slope=0.01, d_residual=None, accumulate_residual=False, ws=None):
     ws = workspace() if ws is None else ws
     check(load().rx_instnorm_act_bwd(_code(y.dtype), byref(g.desc()), byref(y.desc()), _ptr(stats),

@@ -348,9 +348,8 @@ class Plan:
                     f.append(tstep)
                 elif rec.kind == "inact":
                     def step(a=a):
-                        ops.instnorm_stats(a["y"].act, a["stats"], a["eps"])
-                        ops.instnorm_act_fwd(a["y"].act, a["stats"], a["out"].act, a["slope"],
-                                             a["res"].act if a["res"] is not None else None)
+                        ops.instnorm_fwd(a["y"].act, a["stats"], a["out"].act, a["slope"],
+                                         a["res"].act if a["res"] is not None else None, a["eps"])
                     f.append(step)
                 elif rec.kind == "pool":
                     f.append(lambda a=a: ops.avgpool_fwd(a["x"].act, a["y"].act, a["stride"]))

@@ -134,7 +134,8 @@ def test_convT3d_fwd_bwd(ops, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("c,dims", [(32, (8, 8, 8)), (64, (5, 6, 7)), (320, (4, 4, 4)), (512, (2, 2, 2))])
+@pytest.mark.parametrize("c,dims", [(32, (8, 8, 8)), (64, (5, 6, 7)), (320, (4, 4, 4)), (512, (2, 2, 2)),
+                                    (32, (20, 16, 16)), (16, (8, 8, 8)), (96, (16, 16, 16))])   # small + large paths
 def test_instnorm_lrelu_residual(ops, dtype, c, dims):
     n = 2
     y = (rnd((n, c, *dims), dtype, 9) * 2 + 0.5).to(dtype).double()   # keep values representable
@@ -155,6 +156,11 @@ def test_instnorm_lrelu_residual(ops, dtype, c, dims):
         oa = ops.Act.zeros(n, *dims, c, dtype)
         ops.instnorm_act_fwd(ya, stats, oa, slope, ra if with_res else None)
         assert rel(oa.to_ncdhw(), ref.detach()) < TOL[dtype]
+        # fused stats+apply entry point (single launch on small tensors) must agree with the two-call path
+        ob, stats2 = ops.Act.zeros(n, *dims, c, dtype), torch.zeros_like(stats)
+        ops.instnorm_fwd(ya, stats2, ob, slope, ra if with_res else None)
+        assert rel(stats2, stats) < 1e-5
+        assert rel(ob.to_ncdhw(), oa.to_ncdhw()) < (1e-6 if dtype == torch.float32 else TOL[dtype])
         # backward: feed the mask from the reference output (rounded) so both sides agree on signs
         out_ref_act = to_act(ops, ref.detach().to(dtype).double(), dtype)
         ref.backward(g)
