@@ -223,14 +223,13 @@ def main():
         opt.zero_grad(set_to_none=True)
         return loss
 
+    if world == 1 and os.environ.get("RX_GRAPHS", "0") == "1":
+        for _ in range(3):            # plan build + two eager passes + HIP graph capture: never inside the timed region
+            step()
     for _ in range(args.warmup):
         step()
     if rank == 0:
         print(f"[bench] warm-up done, timing {args.steps} steps ...", file=sys.stderr, flush=True)
-    prof = None
-    if not args.no_kernel_timing and rank == 0:
-        prof = ops.LaunchProfiler()
-        ops.set_profiler(prof)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -241,18 +240,32 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ops.set_profiler(None)
+    # Per-kernel durations for the roofline: HIP events around every conv launch, on the stream it is enqueued on, over
+    # `prof_steps` further steps of the same loop right after the timed region (two event records per launch cost
+    # ~4 % of a step: they stay out of `value`; with RX_GRAPHS=1 events cannot be inserted into the replayed graphs
+    # either).  The committed rocprofv3 summary of this command covers the timed steps themselves.
+    prof, prof_steps = None, 0
+    if not args.no_kernel_timing:
+        prof_steps = min(args.steps, 5)
+        if rank == 0:
+            prof = ops.LaunchProfiler()
+            ops.set_profiler(prof)
+        for _ in range(prof_steps):
+            step()
+        torch.cuda.synchronize()
+        ops.set_profiler(None)
     # extra, outside the timed region: the same kernels WITHOUT stream overlap (weight gradients back on the main
     # stream) so that per-kernel durations are free of the contention the overlapped schedule creates on purpose
     iso = None
-    if prof is not None:
-        iso = ops.LaunchProfiler()
+    if not args.no_kernel_timing:
         for plan in net._plans.values():
             plan.overlap_wgrad = False
-        step()
-        ops.set_profiler(iso)
+        if rank == 0:
+            iso = ops.LaunchProfiler()
+            ops.set_profiler(iso)
         for _ in range(2):
             step()
+        torch.cuda.synchronize()
         ops.set_profiler(None)
         for plan in net._plans.values():
             plan.overlap_wgrad = True
@@ -270,8 +283,8 @@ def main():
         if prof is not None:
             groups = prof.collect()
             for name, g in groups.items():
-                kernels[name] = dict(ms_per_step=g["ms"] / args.steps, avg_us_per_launch=g["ms"] * 1e3 / max(g["launches"], 1),
-                                     launches_per_step=g["launches"] / args.steps,
+                kernels[name] = dict(ms_per_step=g["ms"] / prof_steps, avg_us_per_launch=g["ms"] * 1e3 / max(g["launches"], 1),
+                                     launches_per_step=g["launches"] / prof_steps,
                                      tflops=g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0)
             if groups:
                 dom = max(groups, key=lambda k: groups[k]["ms"])
@@ -281,7 +294,8 @@ def main():
                 roofline = dict(bound="mfma", kernel=dom, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
                                 traffic=tr["bytes_per_launch"] if tr else None, traffic_detail=tr,
                                 avg_us_per_launch=g["ms"] * 1e3 / max(g["launches"], 1),
-                                flops_per_launch=g["flops"] / max(g["launches"], 1))
+                                flops_per_launch=g["flops"] / max(g["launches"], 1),
+                                note=f"HIP events over {prof_steps} further steps of the same loop, right after the timed region")
         line = {
             "metric": "train patches/sec (b,c,z,y,x) ResEncM 1x128^3", "value": value, "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -292,6 +306,7 @@ def main():
                                    f"batch {batch}/GPU, full train step (fwd+loss+bwd+allreduce+clip+AdamW)",
                        "global_batch": world * batch, "parallelism": f"dp{world}"},
             "final_loss": final_loss,
+            "hip_graphs": bool(world == 1 and os.environ.get("RX_GRAPHS", "0") == "1"),
             "roofline": roofline,
             "roofline_isolated": None,
             "kernels": kernels,

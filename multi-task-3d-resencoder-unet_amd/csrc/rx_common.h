@@ -149,3 +149,12 @@ struct Mma<float> {
     for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[j], c, 0, 0, 0);
   }
 };
+
+// ---- XCD-aware block order ------------------------------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (observed; a speed assumption only, never correctness), each with its
+// own 4 MiB L2.  Remap the physical linear block id so that every XCD works through one CONTIGUOUS range of logical
+// ids: blocks that share operand panels or halos then meet in the same L2.  Bijective for any grid size G.
+__device__ inline int rx_xcd_remap(int L, int G) {
+  const int x = L & 7, slot = L >> 3, chunk = G >> 3, rem = G & 7;
+  return x * chunk + (x < rem ? x : rem) + slot;
+}

@@ -43,16 +43,20 @@ __device__ inline u32x4 tr_frag(const T* p0, const T* p1) {
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const T* __restrict__ gt, const T* __restrict__ xt, float* __restrict__ slab,
-                                                            const WgHaloGeom g) {
+                                                            float* __restrict__ dw, const WgHaloGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* sG = reinterpret_cast<T*>(smem);                       // [VT][32]
   T* sX = sG + RX_WGH_MAX_VT * 32;                          // [HV][32]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: tr reads need full EXEC
-  const int pr = blockIdx.x / g.panels_c, pc = blockIdx.x - pr * g.panels_c;
+  // logical id = split * PP + panel pair: the PP workgroups of one split read the SAME tiles (different channel panels)
+  // and neighbouring splits share halos -- keep them on one XCD
+  const int PPn = gridDim.x, lid = rx_xcd_remap(blockIdx.y * PPn + blockIdx.x, PPn * gridDim.y);
+  const int split = lid / PPn, pp = lid - split * PPn;
+  const int pr = pp / g.panels_c, pc = pp - pr * g.panels_c;
   const int r0 = pr * 32, c0 = pc * 32;
-  const int t_begin = blockIdx.y * g.tiles_per_split;
+  const int t_begin = split * g.tiles_per_split;
   const int t_end = min(g.NT, t_begin + g.tiles_per_split);
 
   // ---- per-thread staging geometry (tile independent)
@@ -87,7 +91,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const T* __restrict_
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int ksteps = g.VT >> 4;
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // Staging is software pipelined: the global loads of tile i+1 are issued right after tile i has been committed to
+  // LDS and stay in flight (in registers) while tile i's MFMAs run.
+  u32x4 gv[RX_WGH_GPIECES], xv[RX_WGH_XPIECES];
+  auto load_tile = [&](int tile) {
     // tile -> (n, z0, y0, x0)
     int tx = tile % g.tx_n, t1 = tile / g.tx_n;
     int ty = t1 % g.ty_n, t2 = t1 / g.ty_n;
@@ -95,8 +102,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const T* __restrict_
     const int z0 = tz * g.TZ, y0 = ty * g.TY, x0 = tx * g.TX;
     const T* gn = gt + n * g.g_ss + r0;
     const T* xn = xt + n * g.x_ss + c0;
-    // ---- stage: global -> registers
-    u32x4 gv[RX_WGH_GPIECES], xv[RX_WGH_XPIECES];
 #pragma unroll
     for (int p = 0; p < RX_WGH_GPIECES; ++p) {
       int v = (tid >> 2) + 64 * p;
@@ -119,6 +124,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const T* __restrict_
       }
       xv[p] = val;
     }
+  };
+  if (t_begin < t_end) load_tile(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();  // every wave is done reading the previous tile
 #pragma unroll
     for (int p = 0; p < RX_WGH_GPIECES; ++p) {
@@ -131,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const T* __restrict_
       if (xh[p] >= 0) *reinterpret_cast<u32x4*>(sX + row * 32 + chunk * 8) = xv[p];
     }
     __syncthreads();
+    if (tile + 1 < t_end) load_tile(tile + 1);
     // ---- compute: 16-voxel k-steps; this lane supplies rows (voxels) v, v+4 of its 8-voxel half
     for (int s = 0; s < ksteps; ++s) {
       const int v = 16 * s + 8 * h + q4;
@@ -157,13 +166,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const T* __restrict_
     }
   }
 
-  // ---- write the 7 accumulators: slab[split][tap][r0+row][c0+col]
   const int col = lane & 31, fh = lane >> 5;
+  if (g.S == 1) {
+    // ---- single split (low-resolution layers: many panel pairs, few tiles): no slab, no reduce launch.  The panel is
+    // transposed through LDS 16 rows at a time ([16][32][27] floats = 54 KB) and leaves as contiguous 3456-byte runs of
+    // dw[r][c0 .. c0+31][0..26]  (tap stride 27 floats is odd -> the 32 columns of a store hit 32 distinct banks).
+    float* sT = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      __syncthreads();  // tile loop / previous half fully drained
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int t = wave + 4 * j;
+        if (t < 27) {
+#pragma unroll
+          for (int r = 8 * hb; r < 8 * hb + 8; ++r) {
+            const int lr = (r & 3) + 8 * ((r >> 2) & 1) + 4 * fh;  // row within this half
+            sT[(lr * 32 + col) * 27 + t] = acc[j][r];
+          }
+        }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 16 * 216; idx += 256) {   // float4 pieces: 216 per 32-column row run (3456 B, 16-B aligned)
+        const int lr = idx / 216, i = idx - lr * 216;
+        *reinterpret_cast<f32x4*>(dw + ((long)(r0 + 16 * hb + lr) * g.Cc + c0) * 27 + 4 * i) = *reinterpret_cast<const f32x4*>(sT + 4 * idx);
+      }
+    }
+    return;
+  }
+  // ---- write the 7 accumulators: slab[split][tap][r0+row][c0+col]
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
     const int t = wave + 4 * j;
     if (t < 27) {
-      float* out = slab + (((long)blockIdx.y * 27 + t) * g.R + r0) * g.Cc + c0;
+      float* out = slab + (((long)split * 27 + t) * g.R + r0) * g.Cc + c0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
@@ -209,11 +245,12 @@ static int wgh_plan(const rx_act* x, const rx_act* dy, WgHaloGeom* g, size_t ws_
   g->panels_c = g->Cc / 32;
   const long PP = (long)(g->R / 32) * g->panels_c;
   long S = (512 + PP - 1) / PP;
+  if (PP >= 256) S = 1;  // the panel pairs alone fill the chip: accumulate every tile in registers, write dw directly
   if (S > g->NT) S = g->NT;
   if (S < 1) S = 1;
   const size_t slab1 = (size_t)27 * g->R * g->Cc * sizeof(float);
   while (S > 1 && S * slab1 > ws_bytes) --S;
-  if (slab1 > ws_bytes) return 0;
+  if (S > 1 && slab1 > ws_bytes) return 0;
   g->tiles_per_split = (int)((g->NT + S - 1) / S);
   g->S = (g->NT + g->tiles_per_split - 1) / g->tiles_per_split;
   return 1;
@@ -244,7 +281,7 @@ int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw,
                                 (int)lds);
       attr = true;
     }
-    hipLaunchKernelGGL((wgrad_halo_kernel<bf16_t>), grid, dim3(256), lds, st, (const bf16_t*)dy->ptr, (const bf16_t*)x->ptr, (float*)ws, g);
+    hipLaunchKernelGGL((wgrad_halo_kernel<bf16_t>), grid, dim3(256), lds, st, (const bf16_t*)dy->ptr, (const bf16_t*)x->ptr, (float*)ws, dw, g);
   } else {
     static bool attr = false;
     if (!attr) {
@@ -252,9 +289,9 @@ int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw,
                                 (int)lds);
       attr = true;
     }
-    hipLaunchKernelGGL((wgrad_halo_kernel<f16_t>), grid, dim3(256), lds, st, (const f16_t*)dy->ptr, (const f16_t*)x->ptr, (float*)ws, g);
+    hipLaunchKernelGGL((wgrad_halo_kernel<f16_t>), grid, dim3(256), lds, st, (const f16_t*)dy->ptr, (const f16_t*)x->ptr, (float*)ws, dw, g);
   }
-  rx_wgrad_reduce_launch((const float*)ws, g.S, 27, g.R, g.Cc, dw, st);
+  if (g.S > 1) rx_wgrad_reduce_launch((const float*)ws, g.S, 27, g.R, g.Cc, dw, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     rx_set_error("wgrad_halo: %s", hipGetErrorString(e));

@@ -109,10 +109,23 @@ class Plan:
         self._grads: List[Optional[torch.Tensor]] = []
         self.grad_order: List[int] = []       # parameter indices in the order their gradients become ready
         self.grad_sync = None                 # optional engine.ddp.GradSync
-        self.overlap_wgrad = True             # weight gradients on a side HIP stream (off the dependency chain)
+        import os
+        # weight gradients on a side HIP stream (off the dependency chain); RX_OVERLAP_WGRAD=0 keeps one stream
+        self.overlap_wgrad = os.environ.get("RX_OVERLAP_WGRAD", "1") != "0"
         self._side = None
         self._ws2 = None
         self._dy_turn: Dict[tuple, int] = {}
+        self._dy_free: Dict[int, "torch.cuda.Event"] = {}
+        # HIP graphs (opt-in: RX_GRAPHS=1 or plan.use_graphs = True): the forward / backward launch lists are static
+        # (fixed buffers, fixed shapes), so after two eager passes (lazy allocations, kernel attribute calls) each list
+        # is captured once -- side stream, events and weight packing included -- and every later step is a single
+        # hipGraphLaunch instead of ~700 host-side launches (8 ms of host time per cfg2 step -> < 1 ms).  Off by
+        # default: a cfg2 step is GPU-bound (the host runs ahead of the queue), so replaying graphs measured the SAME
+        # step time, and a capture must not race with other threads' HIP calls (e.g. a pin-memory loader thread).
+        self.use_graphs = os.environ.get("RX_GRAPHS", "0") == "1"
+        self._gstate: Dict[tuple, dict] = {}
+        self._x_static = None
+        self._dl_static: Dict[str, torch.Tensor] = {}
         self._build()
 
     # ------------------------------------------------------------------ helpers
@@ -400,7 +413,7 @@ class Plan:
 
         # events guarding the two dy slots of every shape: the side stream's last reader of a slot must be done
         # before the main stream writes that slot again
-        dy_free = {}
+        dy_free = self._dy_free
 
         def side_run(fn, dy_act):
             """run `fn` (weight-gradient launches reading dy_act) on the side stream, ordered after everything the
@@ -553,11 +566,12 @@ class Plan:
             torch.cuda.current_stream().wait_event(ev)
             ent["event"] = None
 
-    def refresh_packs(self):
-        """re-pack every parameter whose version moved.  The packs are pure HBM traffic (1.3 GB at cfg2) while the
+    def refresh_packs(self, force=False):
+        """re-pack every parameter whose version moved (all of them with `force`: inside a captured graph).  The packs are pure HBM traffic (1.3 GB at cfg2) while the
         first stages of the forward pass are MFMA/LDS bound: they run on the side stream in first-use order and each
         consumer conv waits for its own parameter's event."""
-        stale = [e for e in self.packs if not (e["version"] == e["param"]._version and e.get("ptr") == e["param"].data_ptr())]
+        stale = [e for e in self.packs
+                 if force or not (e["version"] == e["param"]._version and e.get("ptr") == e["param"].data_ptr())]
         if not stale:
             return
         side = None
@@ -587,38 +601,77 @@ class Plan:
             ent["version"] = p._version
             ent["ptr"] = p.data_ptr()
 
+    # ---- HIP graph plumbing ---------------------------------------------------------------------------------
+    def _graphs_on(self):
+        # (needs_grad plans only: an inference plan re-packs nothing and has no backward list worth capturing)
+        return (self.use_graphs and self.device.type == "cuda" and self.needs_grad
+                and self.grad_sync is None and ops._PROF is None)
+
+    def _param_ptrs(self):
+        return tuple(p.data_ptr() for p in self.params)
+
+    def _graphed(self, key, body):
+        """run `body` eagerly twice, then capture it once and replay it ever after.  Returns the state dict."""
+        st = self._gstate.setdefault(key, {"calls": 0})
+        ptrs = self._param_ptrs()
+        if st.get("graph") is not None and st["ptrs"] != ptrs:      # parameters were re-allocated: start over
+            st.clear()
+            st["calls"] = 0
+        if st.get("graph") is not None:
+            st["graph"].replay()
+        elif st["calls"] < 2:
+            st["calls"] += 1
+            st["result"] = body()
+            st["eager"] = True
+            return st
+        else:
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["result"] = body()
+            st["graph"], st["ptrs"] = g, ptrs
+            g.replay()
+        st["eager"] = False
+        return st
+
+    def _forward_body(self, force_packs):
+        self.refresh_packs(force=force_packs)
+        for step in self.fwd:
+            step()
+        for ent in self.packs:          # parameters of unused branches: never leave a pack in flight
+            self._await_pack(ent)
+
     def run_forward(self, x, apply_act):
         if tuple(x.shape) != self.in_shape:
             raise ValueError(f"plan built for input {self.in_shape}, got {tuple(x.shape)}")
         x = x.detach()
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
-        self._x = x.unsqueeze(2) if self.two_d else x
         self._apply_act = apply_act
-        self.refresh_packs()
-        for step in self.fwd:
-            step()
-        for ent in self.packs:          # parameters of unused branches: never leave a pack in flight
-            self._await_pack(ent)
+        if self._graphs_on():
+            if self._x_static is None:
+                self._x_static = torch.empty(self.in_shape, dtype=torch.float32, device=self.device)
+            self._x_static.copy_(x)                 # the graph reads a fixed address
+            self._x = self._x_static.unsqueeze(2) if self.two_d else self._x_static
+            st = self._gstate.get(("f", apply_act))
+            capturing = st is not None and st.get("graph") is None and st["calls"] >= 2
+            self._graphed(("f", apply_act), lambda: self._forward_body(force_packs=capturing))
+            st = self._gstate[("f", apply_act)]
+            if not st["eager"]:                       # the graph re-packed every parameter
+                for ent in self.packs:
+                    ent["version"], ent["ptr"], ent["event"] = ent["param"]._version, ent["param"].data_ptr(), None
+        else:
+            self._x = x.unsqueeze(2) if self.two_d else x
+            self._forward_body(force_packs=False)
         self.generation += 1
         outs = {}
         for k, v in self.outputs.items():
             outs[k] = v.squeeze(2) if self.two_d else v
         return outs
 
-    def run_backward(self, dlogits: Dict[str, Optional[torch.Tensor]]):
-        self._dlogits = {}
-        for k, g in dlogits.items():
-            if g is None:
-                continue
-            g = g.detach()
-            if g.dtype != torch.float32 or not g.is_contiguous():
-                g = g.float().contiguous()
-            self._dlogits[k] = g.unsqueeze(2) if self.two_d else g
+    def _backward_body(self):
         self._grads = [None] * len(self.params)
-        if self.overlap_wgrad and self._side is None and self.device.type == "cuda":
-            self._side = torch.cuda.Stream(device=self.device)
-            self._ws2 = torch.empty(ops.workspace().numel(), dtype=torch.uint8, device=self.device)
+        self._dy_free.clear()       # the previous backward ended with main.wait_stream(side): nothing is still read
         if self.grad_sync is not None:
             self.grad_sync.begin(self)
         for step in self.bwd:
@@ -630,3 +683,43 @@ class Plan:
         grads = self._grads
         self._grads = []
         return grads
+
+    def run_backward(self, dlogits: Dict[str, Optional[torch.Tensor]]):
+        graphs = self._graphs_on()
+        self._dlogits = {}
+        for k, g in dlogits.items():
+            if g is None:
+                continue
+            g = g.detach()
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = g.float().contiguous()
+            if graphs:
+                buf = self._dl_static.get(k)
+                if buf is None or buf.shape != g.shape:
+                    buf = self._dl_static[k] = torch.empty_like(g)
+                buf.copy_(g)
+                g = buf
+            self._dlogits[k] = g.unsqueeze(2) if self.two_d else g
+        if self.overlap_wgrad and self._side is None and self.device.type == "cuda":
+            self._side = torch.cuda.Stream(device=self.device)
+            self._ws2 = torch.empty(ops.workspace().numel(), dtype=torch.uint8, device=self.device)
+        if not graphs:
+            return self._backward_body()
+        key = ("b", tuple(sorted(self._dlogits)))
+        st = self._gstate.get(key)
+        if st is not None and st.get("graph") is not None:
+            # the graph rewrites the SAME gradient storage every replay.  autograd normally steals the tensors we
+            # return as .grad; if the caller kept such a .grad (gradient accumulation) move it out of the way first.
+            owned = st["owned"]
+            for p in self.params:
+                gr = p.grad
+                if gr is not None and gr.data_ptr() in owned:
+                    p.grad = gr.clone()
+        st = self._graphed(key, self._backward_body)
+        grads = st["result"]
+        if st["eager"]:
+            return grads
+        if "owned" not in st:
+            st["owned"] = {t.data_ptr() for t in grads if t is not None}
+        # fresh tensor objects over the graph-owned storage (autograd steals a gradient only if nobody else holds it)
+        return [t.detach() if t is not None else None for t in grads]

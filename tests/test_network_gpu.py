@@ -156,3 +156,42 @@ def test_backward_after_overwritten_buffers_is_refused(NetworkFromConfig):
     net(x)                                    # second forward of the same shape reuses the buffers
     with pytest.raises(RuntimeError):
         out1["seg"].sum().backward()
+
+
+def test_hip_graph_replay_is_bit_identical_to_eager(NetworkFromConfig):
+    """opt-in HIP graphs (plan.use_graphs): after two eager passes the forward and backward launch lists are captured
+    and replayed.  Same kernels, same order, deterministic reductions -> parameters after 6 SGD steps must be
+    IDENTICAL to the eager run's; also covered: gradient accumulation across replays (the graph re-writes the storage
+    of the gradients it returned, so a kept .grad is moved out of the way first)."""
+    c = CASES["auto16_2head"]
+
+    def run(use_graphs):
+        net, _, _ = build(NetworkFromConfig, "auto16_2head")
+        net.train()
+        x, targets = oracle.synthetic_batch(c["batch"], c["in_channels"], c["patch"], c["tasks"], 7)
+        x = x.cuda()
+        targets = {k: v.cuda() for k, v in targets.items()}
+        opt = torch.optim.SGD([p for p in net.parameters()], lr=0.05)
+        losses = []
+        for step in range(6):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = net(x)
+            for plan in net._plans.values():
+                plan.use_graphs = use_graphs
+            loss = oracle.train_loss(out, targets, c["tasks"])
+            loss.backward()
+            if step == 4:
+                continue          # no optimizer step / zero_grad: step 5 ACCUMULATES into the kept gradients
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            losses.append(loss.item())
+        if use_graphs:
+            states = [st for plan in net._plans.values() for st in plan._gstate.values()]
+            assert states and all(st.get("graph") is not None for st in states), "graphs were never captured"
+        return losses, {n: p.detach().clone() for n, p in net.named_parameters()}
+
+    l_e, p_e = run(False)
+    l_g, p_g = run(True)
+    assert l_e == l_g
+    for n in p_e:
+        assert torch.equal(p_e[n], p_g[n]), n

@@ -53,6 +53,8 @@ CONV_CASES = [
     (32, 32, (5, 8, 8), (1, 3, 3), (1, 1, 1)),        # anisotropic kernel
     (64, 32, (8, 8, 8), (1, 1, 1), (1, 1, 1)),        # 1x1x1 projection
     (256, 256, (4, 4, 4), (3, 3, 3), (1, 1, 1)),      # deep layer: few voxels -> split-K path
+    (512, 512, (4, 4, 4), (3, 3, 3), (1, 1, 1)),      # bottleneck: 256 panel pairs -> single-split direct wgrad epilogue
+    (512, 512, (3, 8, 8), (3, 3, 3), (1, 1, 1)),      # same, several (ragged) tiles per workgroup
 ]
 
 
