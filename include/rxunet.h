@@ -133,6 +133,24 @@ int rx_channel_sum(rx_dtype dt, const rx_act* x, float* out, void* ws, size_t ws
 /* ---- fused train-step losses on NCDHW fp32 logits (training/losses/losses.py) ----------- */
 /* reserved for a later round; see DESIGN.md "next" */
 
+/* ---- task losses of the train step, single pass (reference training/losses/losses.py) ---------
+ * logits / target / pred: (N, C, V) fp32, NCDHW-contiguous (V = Z*Y*X).  `loss` and `grad_loss` are DEVICE scalars
+ * (no host synchronisation); `coef` carries the per-channel backward coefficients from fwd to bwd
+ * (2*C floats for BCE-Dice, 1 float for masked cosine).  ws: rx_loss_workspace() bytes. */
+size_t rx_loss_workspace(int n, int c, long v);
+/* BCEDiceLoss(alpha, beta): alpha * BCE-with-logits on targets t*(1-2s)+s (losses.py:217-238,307-318)
+ * + beta * (1 - mean_c 2 sum(p t) / max(sum(p^2)+sum(t^2), eps)), p = sigmoid(logits) (losses.py:17-43,128-138) */
+int rx_bce_dice_loss_fwd(const float* logits, const float* target, int n, int c, long v, float alpha, float beta,
+                         float smoothing, float eps, float* loss, float* coef, void* ws, size_t ws_bytes,
+                         void* stream);
+int rx_bce_dice_loss_bwd(const float* logits, const float* target, int n, int c, long v, float alpha, float beta,
+                         float smoothing, const float* coef, const float* grad_loss, float* dlogits, void* stream);
+/* MaskedCosineLoss (losses.py:187-215): 1 - sum(cos(pred/|pred|, t) m) / (sum(m) + 1e-8), m = |t| > 1e-6; C <= 8 */
+int rx_masked_cosine_loss_fwd(const float* pred, const float* target, int n, int c, long v, float* loss, float* coef,
+                              void* ws, size_t ws_bytes, void* stream);
+int rx_masked_cosine_loss_bwd(const float* pred, const float* target, int n, int c, long v, const float* coef,
+                              const float* grad_loss, float* dpred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

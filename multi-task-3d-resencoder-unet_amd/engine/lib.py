@@ -2,7 +2,7 @@
 missing -- there is no fallback path."""
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
 
 import torch
 
@@ -62,6 +62,14 @@ _SIGNATURES = {
                             c_void_p]),
     "rx_channel_sum_workspace": (c_size_t, [_P]),
     "rx_channel_sum": (c_int, [c_int, _P, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rx_loss_workspace": (c_size_t, [c_int, c_int, c_long]),
+    "rx_bce_dice_loss_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_float, c_float, c_float, c_float, c_void_p,
+                                     c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rx_bce_dice_loss_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_float, c_float, c_float, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]),
+    "rx_masked_cosine_loss_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p, c_size_t,
+                                          c_void_p]),
+    "rx_masked_cosine_loss_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -295,3 +295,46 @@ def channel_sum(x, out, ws=None):
     ws = workspace() if ws is None else ws
     check(load().rx_channel_sum(_code(x.dtype), byref(x.desc()), _ptr(out), *_ws_args(ws), stream_ptr()),
           "rx_channel_sum")
+
+
+# ---- task losses (single-pass kernels; loss value and upstream gradient stay on the device) ------
+def _ncv(t):
+    n, c = t.shape[0], t.shape[1]
+    return n, c, t.numel() // (n * c)
+
+
+def bce_dice_loss_fwd(logits, target, alpha, beta, smoothing=0.1, eps=1e-6):
+    """-> (loss: 0-dim fp32 device tensor, coef: (2*C,) fp32 for the backward)"""
+    n, c, v = _ncv(logits)
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    coef = torch.empty(2 * c, dtype=torch.float32, device=logits.device)
+    ws = workspace(load().rx_loss_workspace(n, c, v))
+    check(load().rx_bce_dice_loss_fwd(_ptr(logits), _ptr(target), n, c, v, alpha, beta, smoothing, eps, _ptr(loss), _ptr(coef),
+                                      *_ws_args(ws), stream_ptr()), "rx_bce_dice_loss_fwd")
+    return loss, coef
+
+
+def bce_dice_loss_bwd(logits, target, coef, grad_loss, alpha, beta, smoothing=0.1):
+    n, c, v = _ncv(logits)
+    dlogits = torch.empty_like(logits)
+    check(load().rx_bce_dice_loss_bwd(_ptr(logits), _ptr(target), n, c, v, alpha, beta, smoothing, _ptr(coef), _ptr(grad_loss),
+                                      _ptr(dlogits), stream_ptr()), "rx_bce_dice_loss_bwd")
+    return dlogits
+
+
+def masked_cosine_loss_fwd(pred, target):
+    n, c, v = _ncv(pred)
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)
+    coef = torch.empty(1, dtype=torch.float32, device=pred.device)
+    ws = workspace(load().rx_loss_workspace(n, c, v))
+    check(load().rx_masked_cosine_loss_fwd(_ptr(pred), _ptr(target), n, c, v, _ptr(loss), _ptr(coef), *_ws_args(ws), stream_ptr()),
+          "rx_masked_cosine_loss_fwd")
+    return loss, coef
+
+
+def masked_cosine_loss_bwd(pred, target, coef, grad_loss):
+    n, c, v = _ncv(pred)
+    dpred = torch.empty_like(pred)
+    check(load().rx_masked_cosine_loss_bwd(_ptr(pred), _ptr(target), n, c, v, _ptr(coef), _ptr(grad_loss), _ptr(dpred),
+                                           stream_ptr()), "rx_masked_cosine_loss_bwd")
+    return dpred
