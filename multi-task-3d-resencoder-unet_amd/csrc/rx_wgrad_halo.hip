@@ -156,13 +156,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const T* __restrict_
       const u32x4 a = tr_frag<T>(sG + v * 32 + coloff, sG + (v + 4) * 32 + coloff);
       const T* b0 = sX + hr * 32 + coloff;
       const T* b1 = sX + hr4 * 32 + coloff;
+      // all fragment reads of the k-step are issued before its first MFMA (distinct registers): the LDS latency is
+      // paid once per 7 MFMAs instead of once per MFMA (the compiler otherwise recycles ONE fragment register set and
+      // brackets every MFMA with s_waitcnt lgkmcnt(0))
+      u32x4 bf[7];
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        if (j < 6 || wave < 3) {
-          const u32x4 b = tr_frag<T>(b0 + toff[j], b1 + toff[j]);
-          Mma<T>::run(acc[j], a, b);
-        }
-      }
+      for (int j = 0; j < 7; ++j)
+        if (j < 6 || wave < 3) bf[j] = tr_frag<T>(b0 + toff[j], b1 + toff[j]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 7; ++j)
+        if (j < 6 || wave < 3) Mma<T>::run(acc[j], a, bf[j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
