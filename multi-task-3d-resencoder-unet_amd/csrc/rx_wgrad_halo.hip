@@ -14,6 +14,10 @@
 //   * 7 x 32x32 fp32 accumulators per wave live in registers across ALL tiles of the workgroup's split and
 //     are written once as slab[split][tap][R][C]; the fixed-order reduce of rx_wgrad.hip finishes.
 // Two workgroups per CU (<= 62 KB LDS each) overlap one's staging with the other's MFMAs.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "rx_common.h"
 
 struct WgHaloGeom {
@@ -24,6 +28,7 @@ struct WgHaloGeom {
   int HY, HX, HV, VT;
   int tz_n, ty_n, tx_n, NT;
   int S, tiles_per_split, panels_c;
+  int dbg;   // ablation mask (RX_DBG env): 1 stage only the first tile, 2 no MFMA loop
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_h;
@@ -214,6 +219,216 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const T* __restrict_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Specialisation for the 4 x 4 x 16 tile (every layer whose X extent is >= 16: 92 % of the weight-gradient FLOPs).
+// SQ counters of the generic kernel above: 9.3 VALU instructions per MFMA (voxel decode and one address add per
+// fragment read) -- with two waves per SIMD the VALU, not the matrix pipe (38 % busy), was the bound.  Here the tile
+// geometry AND the wave's tap set are compile-time constants (one instantiation per wave index, chosen by a scalar
+// branch), the 16 k-steps are unrolled, and every fragment address is  lane_base + IMMEDIATE  in the ds_read offset
+// field: the MFMA loop contains no address arithmetic at all.  Fragment reads are double buffered across k-steps.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+
+__device__ inline u32x4 tr_frag_at(const lds_byte* p, int off0, int off1) {
+  s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_h*)(p + off0));
+  s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_h*)(p + off1));
+  u32x2 lo = __builtin_bit_cast(u32x2, t0), hi = __builtin_bit_cast(u32x2, t1);
+  return u32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
+#define WGH16_HY 6
+#define WGH16_HX 18
+#define WGH16_HV 648
+#define WGH16_XPIECES 11   // ceil(648 * 4 / 256)
+
+// gb: lane base into sG (row 8h+q4 of k-step 0), xb: lane base into sX (halo row (0,0,8h+q4) i.e. tap (-1,-1,-1) of
+// voxel (0,0,8h+q4)); both include the lane's column offset.  Rows are 64 bytes.  `stage(s)` is called once per k-step
+// between the MFMAs: the caller uses it to issue one piece of the NEXT tile's global loads, so that their address
+// arithmetic (VALU) and latency disappear behind the matrix pipe.
+template <typename T, int W, typename Stage>
+__device__ __forceinline__ void wgh16_tile_mma(const lds_byte* gb, const lds_byte* xb, f32x16 (&acc)[7], Stage&& stage) {
+  constexpr int NT = W < 3 ? 7 : 6;
+  // Rolling single buffer: the fragment of tap j for k-step s+1 is read into the registers of tap j right after the
+  // MFMA of (s, j) has issued, i.e. 7 MFMAs (~220 cycles) before its consumer -- the whole LDS latency is hidden with
+  // one B register set; only the A fragment (shared by the 7 MFMAs of a step) is double buffered.
+  u32x4 fa[2], fb[7];
+  auto read_a = [&](int s) { return tr_frag_at(gb, s * 1024, s * 1024 + 256); };
+  auto read_b = [&](int s, int j) {
+    const int vy = s & 3, vz = s >> 2;
+    const int t = W + 4 * j;
+    const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;                   // 0..2 (the lane base sits at tap (-1,-1,-1))
+    const int off = (((vz + dz) * WGH16_HY + (vy + dy)) * WGH16_HX + dx) * 64;
+    return tr_frag_at(xb, off, off + 256);
+  };
+  fa[0] = read_a(0);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) fb[j] = read_b(0, j);
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    if (s + 1 < 16) fa[(s + 1) & 1] = read_a(s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      Mma<T>::run(acc[j], fa[s & 1], fb[j]);
+      if (s + 1 < 16) fb[j] = read_b(s + 1, j);
+      __builtin_amdgcn_sched_barrier(0);   // pin the pair: the scheduler otherwise sinks every read to just before its
+                                           // consumer, recycles ONE register set and brackets each MFMA with lgkmcnt(0)
+    }
+    stage(s);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+#define WGH16_BUF_BYTES ((256 + WGH16_HV) * 64)   // one (dY tile, X halo tile) pair: 57,856 bytes
+
+// One workgroup per CU (the pipelined loop wants ~370 registers per lane).  Measured and rejected: a second LDS tile buffer
+// (one barrier per tile) and issuing the next tile's loads piecewise between the MFMAs -- 4-14 % slower in isolation, and
+// a 115 KB workgroup no longer shares a CU with the main stream's convolutions (+1.2 ms per cfg2 step).
+template <typename T>
+__global__ __launch_bounds__(256, 1) void wgrad_halo16_kernel(const T* __restrict__ gt, const T* __restrict__ xt, float* __restrict__ slab,
+                                                              float* __restrict__ dw, const WgHaloGeom g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // sG [256][32], sX [648][32]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int PPn = gridDim.x, lid = rx_xcd_remap(blockIdx.y * PPn + blockIdx.x, PPn * gridDim.y);
+  const int split = lid / PPn, pp = lid - split * PPn;
+  const int pr = pp / g.panels_c, pc = pp - pr * g.panels_c;
+  const int r0 = pr * 32, c0 = pc * 32;
+  const int t_begin = split * g.tiles_per_split;
+  const int t_end = min(g.NT, t_begin + g.tiles_per_split);
+
+  const int chunk = tid & 3;
+  int xh[WGH16_XPIECES];                                     // packed halo coordinates (hz<<16 | hy<<8 | hx), -1 = none
+#pragma unroll
+  for (int p = 0; p < WGH16_XPIECES; ++p) {
+    const int row = (tid >> 2) + 64 * p;
+    const int hx = row % WGH16_HX, t = row / WGH16_HX;
+    xh[p] = row < WGH16_HV ? ((t / WGH16_HY) << 16) | ((t % WGH16_HY) << 8) | hx : -1;
+  }
+  const int g16 = lane >> 4, half = g16 & 1, h = g16 >> 1, l15 = lane & 15, q4 = l15 >> 2, p4 = l15 & 3;
+  const int lane_off = ((8 * h + q4) * 32 + 16 * half + 4 * p4) * 2;   // bytes: row 8h+q4, this lane's 4-channel column group
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // ---- staging: 15 sixteen-byte pieces per thread and tile (4 of dY, 11 of the X halo)
+  u32x4 gv[4], xv[WGH16_XPIECES];
+  int s_z0 = 0, s_y0 = 0, s_x0 = 0;
+  const T* s_gn = gt;
+  const T* s_xn = xt;
+  auto set_tile = [&](int tile) {       // wave-uniform decode of the tile being staged
+    int tx = tile % g.tx_n, t1 = tile / g.tx_n;
+    int ty = t1 % g.ty_n, t2 = t1 / g.ty_n;
+    int tz = t2 % g.tz_n, n = t2 / g.tz_n;
+    s_z0 = tz * 4, s_y0 = ty * 4, s_x0 = tx * 16;
+    s_gn = gt + n * g.g_ss + r0 + chunk * 8;
+    s_xn = xt + n * g.x_ss + c0 + chunk * 8;
+  };
+  auto issue_piece = [&](int p) {       // p in [0, 15); p is a compile-time constant at every call site
+    if (p < 4) {
+      const int v = (tid >> 2) + 64 * p;
+      const int z = s_z0 + (v >> 6), y = s_y0 + ((v >> 4) & 3), x = s_x0 + (v & 15);
+      u32x4 val = u32x4{0u, 0u, 0u, 0u};
+      if (z < g.Z && y < g.Y && x < g.X) val = *reinterpret_cast<const u32x4*>(s_gn + ((long)(z * g.Y + y) * g.X + x) * g.ldg);
+      gv[p] = val;
+    } else {
+      const int q = p - 4;
+      u32x4 val = u32x4{0u, 0u, 0u, 0u};
+      if (xh[q] >= 0) {
+        const int z = s_z0 + (xh[q] >> 16) - 1, y = s_y0 + ((xh[q] >> 8) & 255) - 1, x = s_x0 + (xh[q] & 255) - 1;
+        if ((unsigned)z < (unsigned)g.Z && (unsigned)y < (unsigned)g.Y && (unsigned)x < (unsigned)g.X)
+          val = *reinterpret_cast<const u32x4*>(s_xn + ((long)(z * g.Y + y) * g.X + x) * g.ldx);
+      }
+      xv[q] = val;
+    }
+  };
+  auto commit = [&](int buf) {          // staged registers -> LDS buffer `buf`
+    T* sG = reinterpret_cast<T*>(smem + buf * WGH16_BUF_BYTES);
+    T* sX = sG + 256 * 32;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(sG + ((tid >> 2) + 64 * p) * 32 + chunk * 8) = gv[p];
+#pragma unroll
+    for (int p = 0; p < WGH16_XPIECES; ++p)
+      if (xh[p] >= 0) *reinterpret_cast<u32x4*>(sX + ((tid >> 2) + 64 * p) * 32 + chunk * 8) = xv[p];
+  };
+
+  if (t_begin < t_end) {
+    set_tile(t_begin);
+#pragma unroll
+    for (int p = 0; p < 15; ++p) issue_piece(p);
+  }
+  const lds_byte* gb = (const lds_byte*)(smem) + lane_off;
+  const lds_byte* xb = gb + 256 * 64;
+  auto stage = [](int) {};
+  // The WHOLE tile loop sits inside the per-wave arm: with the switch inside the loop the accumulators crossed a phi
+  // at every iteration and were copied AGPR <-> VGPR once per tile (112 v_accvgpr moves = 1 VALU op per MFMA).
+  auto run = [&](auto wc) {
+    constexpr int W = decltype(wc)::value;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      if (!(g.dbg & 1) || tile == t_begin) {
+        __syncthreads();          // every wave is done reading the previous tile
+        commit(0);
+        __syncthreads();
+        if (tile + 1 < t_end) {   // the next tile's loads stay in flight (in registers) behind this tile's MFMAs
+          set_tile(tile + 1);
+#pragma unroll
+          for (int p = 0; p < 15; ++p) issue_piece(p);
+        }
+      }
+      if (!(g.dbg & 2)) wgh16_tile_mma<T, W>(gb, xb, acc, stage);
+    }
+  };
+  switch (wave) {   // scalar branch: the tap set of a wave is a compile-time constant inside each arm
+    case 0: run(std::integral_constant<int, 0>{}); break;
+    case 1: run(std::integral_constant<int, 1>{}); break;
+    case 2: run(std::integral_constant<int, 2>{}); break;
+    default: run(std::integral_constant<int, 3>{}); break;
+  }
+
+  const int col = lane & 31, fh = lane >> 5;
+  if (g.S == 1) {   // single split: transpose through LDS, contiguous runs of dw (see the generic kernel)
+    float* sT = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int t = wave + 4 * j;
+        if (t < 27) {
+#pragma unroll
+          for (int r = 8 * hb; r < 8 * hb + 8; ++r) {
+            const int lr = (r & 3) + 8 * ((r >> 2) & 1) + 4 * fh;
+            sT[(lr * 32 + col) * 27 + t] = acc[j][r];
+          }
+        }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 16 * 216; idx += 256) {
+        const int lr = idx / 216, i = idx - lr * 216;
+        *reinterpret_cast<f32x4*>(dw + ((long)(r0 + 16 * hb + lr) * g.Cc + c0) * 27 + 4 * i) = *reinterpret_cast<const f32x4*>(sT + 4 * idx);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int t = wave + 4 * j;
+    if (t < 27) {
+      float* out = slab + (((long)split * 27 + t) * g.R + r0) * g.Cc + c0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+        out[(long)row * g.Cc + col] = acc[j][r];
+      }
+    }
+  }
+}
+
 static int p2ceil(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -278,6 +493,35 @@ int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw,
   if (!wgh_plan(x, dy, &g, ws_bytes)) return 0;
   const size_t lds = (size_t)(RX_WGH_MAX_VT + RX_WGH_MAX_HV) * 64;
   dim3 grid((g.R / 32) * g.panels_c, g.S);
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("RX_DBG");
+      dbg = e ? atoi(e) : 0;
+    }
+    g.dbg = dbg;
+  }
+  if (g.TZ == 4 && g.TY == 4 && g.TX == 16) {   // compile-time tile
+    rx_note_kernel("wgrad_halo16_kernel");
+    const size_t lds16 = (size_t)WGH16_BUF_BYTES;
+    static bool attr16 = false;
+    if (!attr16) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+      attr16 = true;
+    }
+    if (dt == RX_BF16)
+      hipLaunchKernelGGL((wgrad_halo16_kernel<bf16_t>), grid, dim3(256), lds16, st, (const bf16_t*)dy->ptr, (const bf16_t*)x->ptr, (float*)ws, dw, g);
+    else
+      hipLaunchKernelGGL((wgrad_halo16_kernel<f16_t>), grid, dim3(256), lds16, st, (const f16_t*)dy->ptr, (const f16_t*)x->ptr, (float*)ws, dw, g);
+    if (g.S > 1) rx_wgrad_reduce_launch((const float*)ws, g.S, 27, g.R, g.Cc, dw, st);
+    hipError_t e16 = hipGetLastError();
+    if (e16 != hipSuccess) {
+      rx_set_error("wgrad_halo16: %s", hipGetErrorString(e16));
+      return RX_ELAUNCH;
+    }
+    return 1;
+  }
   rx_note_kernel("wgrad_halo_kernel");
   if (dt == RX_BF16) {
     static bool attr = false;

@@ -7,7 +7,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_long, c_size_t,
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "librxunet.so")
+# RX_LIBRARY: an alternative build of the SAME library (kernel A/B runs on one box; device clocks differ box to box)
+LIB_PATH = os.environ.get("RX_LIBRARY") or os.path.join(os.path.dirname(_HERE), "csrc", "librxunet.so")
 
 RX_F32, RX_BF16, RX_F16 = 0, 1, 2
 RX_ACT_NONE, RX_ACT_SIGMOID, RX_ACT_SOFTMAX = 0, 1, 2
