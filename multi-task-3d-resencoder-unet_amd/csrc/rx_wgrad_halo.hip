@@ -429,6 +429,159 @@ __global__ __launch_bounds__(256, 1) void wgrad_halo16_kernel(const T* __restric
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised variant of the 4x4x16 kernel: 512 threads = 4 CONSUMER waves (the MFMA loop above, 7 taps each, no
+// staging registers) + 4 PRODUCER waves (global -> registers -> LDS for the next tile), one of each per SIMD, over two
+// LDS tile buffers and ONE barrier per tile.  Ablation of the 256-thread kernel: MFMA loop alone 221 us, staging alone
+// 193 us, together 343 us (32->32 @128^3): in a single instruction stream the two only overlap by the load latency.
+// Here the producers' address arithmetic, load waits and ds_writes run beside the consumers' MFMAs.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512, 1) void wgrad_halo16ws_kernel(const T* __restrict__ gt, const T* __restrict__ xt, float* __restrict__ slab,
+                                                                float* __restrict__ dw, const WgHaloGeom g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x { sG [256][32], sX [648][32] }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // 0-3 consumers, 4-7 producers
+  const int PPn = gridDim.x, lid = rx_xcd_remap(blockIdx.y * PPn + blockIdx.x, PPn * gridDim.y);
+  const int split = lid / PPn, pp = lid - split * PPn;
+  const int pr = pp / g.panels_c, pc = pp - pr * g.panels_c;
+  const int r0 = pr * 32, c0 = pc * 32;
+  const int t_begin = split * g.tiles_per_split;
+  const int t_end = min(g.NT, t_begin + g.tiles_per_split);
+
+  f32x16 acc[7];
+  if (wave >= 4) {
+    // ================================= producers =================================
+    const int ptid = tid - 256, chunk = ptid & 3;
+    int xh[WGH16_XPIECES];
+#pragma unroll
+    for (int p = 0; p < WGH16_XPIECES; ++p) {
+      const int row = (ptid >> 2) + 64 * p;
+      const int hx = row % WGH16_HX, t = row / WGH16_HX;
+      xh[p] = row < WGH16_HV ? ((t / WGH16_HY) << 16) | ((t % WGH16_HY) << 8) | hx : -1;
+    }
+    u32x4 gv[4], xv[WGH16_XPIECES];
+    auto load_tile = [&](int tile) {
+      int tx = tile % g.tx_n, t1 = tile / g.tx_n;
+      int ty = t1 % g.ty_n, t2 = t1 / g.ty_n;
+      int tz = t2 % g.tz_n, n = t2 / g.tz_n;
+      const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
+      const T* gn = gt + n * g.g_ss + r0 + chunk * 8;
+      const T* xn = xt + n * g.x_ss + c0 + chunk * 8;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int v = (ptid >> 2) + 64 * p;
+        const int z = z0 + (v >> 6), y = y0 + ((v >> 4) & 3), x = x0 + (v & 15);
+        u32x4 val = u32x4{0u, 0u, 0u, 0u};
+        if (z < g.Z && y < g.Y && x < g.X) val = *reinterpret_cast<const u32x4*>(gn + ((long)(z * g.Y + y) * g.X + x) * g.ldg);
+        gv[p] = val;
+      }
+#pragma unroll
+      for (int p = 0; p < WGH16_XPIECES; ++p) {
+        u32x4 val = u32x4{0u, 0u, 0u, 0u};
+        if (xh[p] >= 0) {
+          const int z = z0 + (xh[p] >> 16) - 1, y = y0 + ((xh[p] >> 8) & 255) - 1, x = x0 + (xh[p] & 255) - 1;
+          if ((unsigned)z < (unsigned)g.Z && (unsigned)y < (unsigned)g.Y && (unsigned)x < (unsigned)g.X)
+            val = *reinterpret_cast<const u32x4*>(xn + ((long)(z * g.Y + y) * g.X + x) * g.ldx);
+        }
+        xv[p] = val;
+      }
+    };
+    auto commit = [&](int buf) {
+      T* sG = reinterpret_cast<T*>(smem + buf * WGH16_BUF_BYTES);
+      T* sX = sG + 256 * 32;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(sG + ((ptid >> 2) + 64 * p) * 32 + chunk * 8) = gv[p];
+#pragma unroll
+      for (int p = 0; p < WGH16_XPIECES; ++p)
+        if (xh[p] >= 0) *reinterpret_cast<u32x4*>(sX + ((ptid >> 2) + 64 * p) * 32 + chunk * 8) = xv[p];
+    };
+    if (t_begin < t_end) {
+      load_tile(t_begin);
+      commit(0);
+      if (t_begin + 1 < t_end) load_tile(t_begin + 1);
+    }
+    __syncthreads();                                   // tile 0 visible
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const int buf = (tile - t_begin) & 1;
+      if (tile + 1 < t_end) {
+        commit(buf ^ 1);                               // its readers passed the barrier that ended the previous iteration
+        if (tile + 2 < t_end) load_tile(tile + 2);     // in flight during the next iteration's commit-free time
+      }
+      __syncthreads();
+    }
+  } else {
+    // ================================= consumers =================================
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int g16 = lane >> 4, half = g16 & 1, h = g16 >> 1, l15 = lane & 15, q4 = l15 >> 2, p4 = l15 & 3;
+    const int lane_off = ((8 * h + q4) * 32 + 16 * half + 4 * p4) * 2;
+    auto stage = [](int) {};
+    auto run = [&](auto wc) {
+      constexpr int W = decltype(wc)::value;
+      __syncthreads();                                 // tile 0 visible
+      for (int tile = t_begin; tile < t_end; ++tile) {
+        const int buf = (tile - t_begin) & 1;
+        const lds_byte* gb = (const lds_byte*)(smem) + buf * WGH16_BUF_BYTES + lane_off;
+        if (!(g.dbg & 2)) wgh16_tile_mma<T, W>(gb, gb + 256 * 64, acc, stage);
+        __syncthreads();
+      }
+    };
+    switch (wave) {
+      case 0: run(std::integral_constant<int, 0>{}); break;
+      case 1: run(std::integral_constant<int, 1>{}); break;
+      case 2: run(std::integral_constant<int, 2>{}); break;
+      default: run(std::integral_constant<int, 3>{}); break;
+    }
+  }
+
+  // ---- epilogue: the consumers own the accumulators; every thread helps with the copy-out of the single-split path
+  const int col = lane & 31, fh = lane >> 5;
+  if (g.S == 1) {
+    float* sT = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      __syncthreads();
+      if (wave < 4) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          const int t = wave + 4 * j;
+          if (t < 27) {
+#pragma unroll
+            for (int r = 8 * hb; r < 8 * hb + 8; ++r) {
+              const int lr = (r & 3) + 8 * ((r >> 2) & 1) + 4 * fh;
+              sT[(lr * 32 + col) * 27 + t] = acc[j][r];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 16 * 216; idx += 512) {
+        const int lr = idx / 216, i = idx - lr * 216;
+        *reinterpret_cast<f32x4*>(dw + ((long)(r0 + 16 * hb + lr) * g.Cc + c0) * 27 + 4 * i) = *reinterpret_cast<const f32x4*>(sT + 4 * idx);
+      }
+    }
+    return;
+  }
+  if (wave < 4) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int t = wave + 4 * j;
+      if (t < 27) {
+        float* out = slab + (((long)split * 27 + t) * g.R + r0) * g.Cc + c0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+          out[(long)row * g.Cc + col] = acc[j][r];
+        }
+      }
+    }
+  }
+}
+
 static int p2ceil(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -505,12 +658,21 @@ int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw,
     rx_note_kernel("wgrad_halo16_kernel");
     const size_t lds16 = (size_t)WGH16_BUF_BYTES;
     static bool attr16 = false;
+    static int ws_mode = 1;
     if (!attr16) {
+      const char* e = getenv("RX_WGH_WS");
+      ws_mode = e ? atoi(e) : 1;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16ws_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds16));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16ws_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds16));
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
       attr16 = true;
     }
-    if (dt == RX_BF16)
+    if (ws_mode && dt == RX_BF16)
+      hipLaunchKernelGGL((wgrad_halo16ws_kernel<bf16_t>), grid, dim3(512), 2 * lds16, st, (const bf16_t*)dy->ptr, (const bf16_t*)x->ptr, (float*)ws, dw, g);
+    else if (ws_mode)
+      hipLaunchKernelGGL((wgrad_halo16ws_kernel<f16_t>), grid, dim3(512), 2 * lds16, st, (const f16_t*)dy->ptr, (const f16_t*)x->ptr, (float*)ws, dw, g);
+    else if (dt == RX_BF16)
       hipLaunchKernelGGL((wgrad_halo16_kernel<bf16_t>), grid, dim3(256), lds16, st, (const bf16_t*)dy->ptr, (const bf16_t*)x->ptr, (float*)ws, dw, g);
     else
       hipLaunchKernelGGL((wgrad_halo16_kernel<f16_t>), grid, dim3(256), lds16, st, (const f16_t*)dy->ptr, (const f16_t*)x->ptr, (float*)ws, dw, g);
