@@ -12,6 +12,8 @@
 // MFMA orientation and epilogue are those of rx_igemm.hip (weights = A operand, voxels = accumulator lanes).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "rx_common.h"
 
 struct ConvHaloGeom {
@@ -121,10 +123,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const T* __restrict__
 
   // ---- fragment geometry: this lane's voxel in each of its MV blocks -> halo row
   const int fr = lane & 31, fh = lane >> 5;
+  // TX == 16: deal voxels to lanes so that each ds_read_b128 lane group reads 16 consecutive (swizzle-conflict-free) rows
+  const int fv = g.TX == 16 ? lane_voxel(fr) : fr;
   int hrow[MV];
 #pragma unroll
   for (int b = 0; b < MV; ++b) {
-    int v = (wave * MV + b) * 32 + fr;
+    int v = (wave * MV + b) * 32 + fv;
     int vx = v & (g.TX - 1), vy = (v >> g.lTX) & (g.TY - 1), vz = v >> (g.lTX + g.lTY);
     hrow[b] = ((vz + 1) * g.HY + (vy + 1)) * g.HX + vx + 1;
   }
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const T* __restrict__
   // ---- epilogue (as rx_igemm.hip): lane = voxel, 4 runs of 4 consecutive channels per 32-block
 #pragma unroll
   for (int b = 0; b < MV; ++b) {
-    int v = (wave * MV + b) * 32 + fr;
+    int v = (wave * MV + b) * 32 + fv;
     int vx = v & (g.TX - 1), vy = (v >> g.lTX) & (g.TY - 1), vz = v >> (g.lTX + g.lTY);
     int z = z0 + vz, y = y0 + vy, x = x0 + vx;
     if (z >= g.Z || y >= g.Y || x >= g.X) continue;
