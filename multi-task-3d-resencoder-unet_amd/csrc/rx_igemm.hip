@@ -17,6 +17,8 @@
 // buffering (global loads of tile k+1 in flight under the MFMAs of tile k).
 // Optional split-K (deep 4^3/8^3 layers: few voxels, 14 MB of weights): fp32 slabs + a
 // deterministic reduce kernel.
+#include <stdlib.h>
+
 #include "rx_common.h"
 
 
@@ -224,6 +226,133 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// Low-resolution layers (8^3 / 4^3: N*V <= 2048 voxels, 512 channels, 14 MB of weights per layer).  The kernel above
+// is latency bound there: a 64-byte K tile is only 4 MFMAs per wave between two barriers (~1.5 us per K step), half of a
+// 128-voxel tile is padding at 4^3 (one sample = 64 voxels), and every sample re-reads the weights.  This variant
+//   * folds the batch into M (row Q = n*V + v), so a weight slice is read once per M tile instead of once per sample;
+//   * takes 256-byte K tiles (128 channels of one tap): 16 MFMAs per wave per barrier pair, 4x fewer steps, 4x the
+//     bytes in flight per step; rows are 256 B with the 16-byte chunk index XOR-ed with (row & 15) (conflict free for
+//     the ds_read_b128 lane groups: both operands' 16-lane groups cover 16 distinct row residues, see lane_voxel);
+//   * always splits K (taps x channel groups) so that >= 512 workgroups exist; fp32 slabs + the reduce below.
+// ---------------------------------------------------------------------------------------------
+__device__ inline int lane_voxel_ig(int l) { return l < 4 ? l : l < 12 ? l + 12 : l < 16 ? l - 8 : l < 20 ? l + 8 : l < 28 ? l - 12 : l; }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void igemm_fat_kernel(const T* __restrict__ in, const T* __restrict__ w, float* __restrict__ slab,
+                                                           const IgemmGeom g, int NV /* N * Vq */, int nsteps_total) {
+  constexpr int P = Elem<T>::PER16;
+  constexpr int KC = 16;             // 16-byte chunks per K row (256 B)
+  constexpr int KE = KC * P;         // input channels per K step
+  constexpr int BM = 128, BN = 64;
+  constexpr int XP = BM * KC / 256;  // 8 pieces per thread
+  constexpr int WP = BN * KC / 256;  // 4
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
+  u32x4* sX = reinterpret_cast<u32x4*>(smem_f);          // [BM][KC]
+  u32x4* sW = sX + BM * KC;                              // [BN][KC]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mtiles = (NV + BM - 1) / BM;
+  // the M tiles of one (channel block, K split) read the SAME weight slice: keep them on one XCD (one L2) so that the
+  // slice comes from HBM once, not once per M tile
+  const int lid = rx_xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int mtile = lid % mtiles, rest = lid / mtiles;
+  const int split = rest % g.ksplit, n0 = (rest / g.ksplit) * BN;
+  const IgemmPhase P_ = g.ph[0];
+  const int chunk = tid & 15, rbase = tid >> 4;          // 16 rows per pass
+
+  // ---- per-thread gather geometry: rows rbase + 16p of the M tile
+  int gz[XP], gy[XP], gx[XP];
+  long gbase[XP];
+  bool rok[XP];
+#pragma unroll
+  for (int p = 0; p < XP; ++p) {
+    const int Q = mtile * BM + rbase + 16 * p;
+    rok[p] = Q < NV;
+    const int n = Q / P_.Vq, q = Q - n * P_.Vq;
+    const int qx = q % P_.Qx, t = q / P_.Qx;
+    const int qy = t % P_.Qy, qz = t / P_.Qy;
+    gz[p] = qz * g.isz, gy[p] = qy * g.isy, gx[p] = qx * g.isx;
+    gbase[p] = (long)n * g.in_ss + chunk * P;
+  }
+  const int nkc = g.Ci / KE;
+  const int st_begin = (int)((long)nsteps_total * split / g.ksplit);
+  const int st_end = (int)((long)nsteps_total * (split + 1) / g.ksplit);
+
+  u32x4 xr[XP], wr[WP];
+  auto load_step = [&](int st) {
+    const int tap = st / nkc, cc = st - tap * nkc;
+    const RxTap tp = g.taps[P_.tap0 + tap];
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const int z = gz[p] + tp.dz, y = gy[p] + tp.dy, x = gx[p] + tp.dx;
+      const bool ok = rok[p] && (unsigned)z < (unsigned)g.Zi && (unsigned)y < (unsigned)g.Yi && (unsigned)x < (unsigned)g.Xi;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (ok) v = *reinterpret_cast<const u32x4*>(in + gbase[p] + ((long)(z * g.Yi + y) * g.Xi + x) * g.ldi + cc * KE);
+      xr[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < WP; ++p) {
+      const int row = rbase + 16 * p;
+      wr[p] = *reinterpret_cast<const u32x4*>(w + ((long)tp.w * g.Co + n0 + row) * g.Ci + cc * KE + chunk * P);
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const int row = rbase + 16 * p;
+      sX[row * KC + (chunk ^ (row & 15))] = xr[p];
+    }
+#pragma unroll
+    for (int p = 0; p < WP; ++p) {
+      const int row = rbase + 16 * p;
+      sW[row * KC + (chunk ^ (row & 15))] = wr[p];
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int vrow = wave * 32 + lane_voxel_ig(fr);         // this lane's voxel row of the M tile
+  const u32x4* xrow = sX + vrow * KC;
+  const u32x4* wrow0 = sW + fr * KC;
+  const u32x4* wrow1 = sW + (32 + fr) * KC;
+  const int xm = vrow & 15, wm = fr & 15;                  // (32 + fr) & 15 == fr & 15
+
+  if (st_begin < st_end) load_step(st_begin);
+  for (int st = st_begin; st < st_end; ++st) {
+    __syncthreads();
+    store_step();
+    __syncthreads();
+    if (st + 1 < st_end) load_step(st + 1);
+#pragma unroll
+    for (int ks = 0; ks < KC / 2; ++ks) {
+      const int c = ks * 2 + fh;
+      const u32x4 b = xrow[c ^ xm];
+      const u32x4 a0 = wrow0[c ^ wm], a1 = wrow1[c ^ wm];
+      Mma<T>::run(acc[0], a0, b);
+      Mma<T>::run(acc[1], a1, b);
+    }
+  }
+
+  // ---- fp32 partial sums: slab[split][Q][Co]
+  const int Q = mtile * BM + vrow;
+  if (Q < NV) {
+    float* sp = slab + ((long)split * NV + Q) * g.Co + n0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 v = {acc[a][4 * g4], acc[a][4 * g4 + 1], acc[a][4 * g4 + 2], acc[a][4 * g4 + 3]};
+        *reinterpret_cast<f32x4*>(sp + a * 32 + 8 * g4 + 4 * fh) = v;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 
@@ -264,6 +393,56 @@ static int igemm_launch(rx_dtype dt, const void* in, const void* w, const float*
   }
   nkt_max *= g.Ci / KB;
   if (vmax <= 0 || g.nph <= 0) return RX_OK;
+  // low-resolution layers: fat K steps, batch folded into M (see igemm_fat_kernel)
+  {
+    static int fat_on = -1;
+    if (fat_on < 0) {
+      const char* e = getenv("RX_NO_FAT");
+      fat_on = e ? 0 : 1;
+    }
+    const int KE = 16 * per16;
+    const long NV = (long)N * g.ph[0].Vq;
+    if (fat_on && dt != RX_F32 && g.nph == 1 && g.Ci % KE == 0 && g.Co % 64 == 0 && NV <= 2048 && ws &&
+        g.ph[0].ntaps * (g.Ci / KE) >= 8 && g.ph[0].opz == 0 && g.ph[0].opy == 0 && g.ph[0].opx == 0 && g.osz == 1 && g.osy == 1 &&
+        g.osx == 1) {
+      const int mtiles = (int)((NV + 127) / 128);
+      const int nsteps = g.ph[0].ntaps * (g.Ci / KE);
+      const long base_wgs = (long)mtiles * (g.Co / 64);
+      int ks = (int)((512 + base_wgs - 1) / base_wgs);
+      if (ks > nsteps / 4) ks = nsteps / 4;   // >= 4 K steps per workgroup; also bounds the serial sum of the reduce
+      if (ks < 1) ks = 1;
+      while (ks > 1 && (size_t)ks * NV * g.Co * sizeof(float) > ws_bytes) --ks;
+      if ((size_t)ks * NV * g.Co * sizeof(float) <= ws_bytes) {
+        g.ksplit = ks;
+        g.total_mtiles = mtiles;
+        g.ph[0].mtile0 = 0, g.ph[0].mtiles = mtiles, g.ph[0].slab_off = 0;
+        const size_t lds = (size_t)(128 + 64) * 256;
+        rx_note_kernel("igemm_fat_kernel");
+        dim3 grid(mtiles * ks, g.Co / 64);
+        if (dt == RX_BF16) {
+          static bool attr = false;
+          if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fat_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+          }
+          hipLaunchKernelGGL((igemm_fat_kernel<bf16_t>), grid, dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)w, (float*)ws, g, (int)NV, nsteps);
+        } else {
+          static bool attr = false;
+          if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fat_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+          }
+          hipLaunchKernelGGL((igemm_fat_kernel<f16_t>), grid, dim3(256), lds, st, (const f16_t*)in, (const f16_t*)w, (float*)ws, g, (int)NV, nsteps);
+        }
+        // the reduce always runs here (even for ks == 1 the kernel only writes fp32 slabs): force its split path
+        const long total = NV * (g.Co / 4);
+        const int G = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        RX_DISPATCH_DTYPE(dt, T, hipLaunchKernelGGL((igemm_splitk_reduce<T>), dim3(G, 1), dim3(256), 0, st, (const float*)ws, bias, (T*)out, g, N));
+        RX_CHECK_LAUNCH("igemm_fat");
+        return RX_OK;
+      }
+    }
+  }
   const int BN = (g.Co % 64 == 0) ? 64 : 32;
   const int BM = (vmax <= 128) ? 128 : 256;
   g.total_mtiles = 0;
