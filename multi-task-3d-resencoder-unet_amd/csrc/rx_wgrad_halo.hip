@@ -655,7 +655,6 @@ int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw,
     g.dbg = dbg;
   }
   if (g.TZ == 4 && g.TY == 4 && g.TX == 16) {   // compile-time tile
-    rx_note_kernel("wgrad_halo16_kernel");
     const size_t lds16 = (size_t)WGH16_BUF_BYTES;
     static bool attr16 = false;
     static int ws_mode = 1;
@@ -668,6 +667,7 @@ int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw,
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
       attr16 = true;
     }
+    rx_note_kernel(ws_mode ? "wgrad_halo16ws_kernel" : "wgrad_halo16_kernel");
     if (ws_mode && dt == RX_BF16)
       hipLaunchKernelGGL((wgrad_halo16ws_kernel<bf16_t>), grid, dim3(512), 2 * lds16, st, (const bf16_t*)dy->ptr, (const bf16_t*)x->ptr, (float*)ws, dw, g);
     else if (ws_mode)

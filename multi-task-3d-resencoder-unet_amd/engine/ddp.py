@@ -33,6 +33,9 @@ class GradSync:
         self.bucket_bytes = int(bucket_bytes)
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # RCCL averages inside the collective (ncclAvg; probed on this image with scripts/nccl_avg_probe.py): no
+        # pre-scale pass over the 853 MB of gradients.  gloo has no AVG -> pre-scale by 1/world there.
+        self._native_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self._layout: Dict[int, List[_Bucket]] = {}
         self._cur: Optional[List[_Bucket]] = None
         self._of: Dict[int, _Bucket] = {}
@@ -95,9 +98,12 @@ class GradSync:
             ev.record(torch.cuda.current_stream())
             self._side.wait_event(ev)
             with torch.cuda.stream(self._side):
-                if self.average:
-                    b.flat.div_(self.world)            # pre-scale: sum of (g / world) == mean, no overflow step
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.average and self._native_avg:
+                    b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+                else:
+                    if self.average:
+                        b.flat.div_(self.world)        # pre-scale: sum of (g / world) == mean, no overflow step
+                    b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             b.flat.record_stream(self._side)
         else:
             if self.average:
