@@ -69,32 +69,39 @@ __global__ __launch_bounds__(RX_LOSS_BLOCK) void bce_dice_partial_kernel(const f
 // one block: fp64 combination, loss value, per-channel backward coefficients
 //   coef[2c]   = a_c = 2 / max(D_c, eps)                 d dice_c / d p = a_c t - b_c p
 //   coef[2c+1] = b_c = 4 I_c / D_c^2  (0 where the clamp is active)
-__global__ __launch_bounds__(64) void bce_dice_finalize_kernel(const float* __restrict__ partial, int N, int C, int chunks, double count,
-                                                               float alpha, float beta, float eps, float* __restrict__ loss,
-                                                               float* __restrict__ coef) {
-  __shared__ double sb[64], sd[64];
-  double bce = 0.0, dice = 0.0;
-  for (int c = threadIdx.x; c < C; c += 64) {
+__global__ __launch_bounds__(256) void bce_dice_finalize_kernel(const float* __restrict__ partial, int N, int C, int chunks, double count,
+                                                                float alpha, float beta, float eps, float* __restrict__ loss,
+                                                                float* __restrict__ coef) {
+  // one block; per channel the N*chunks partial quadruples are summed by all 256 threads (fp64), then thread 0 combines
+  __shared__ double red[4][256];
+  double bce = 0.0, dice = 0.0;   // meaningful in thread 0 only
+  for (int c = 0; c < C; ++c) {
     double s[4] = {0, 0, 0, 0};
-    for (int n = 0; n < N; ++n)
-      for (int k = 0; k < chunks; ++k) {
-        const float* p = partial + (((long)n * C + c) * chunks + k) * 4;
-        s[0] += p[0], s[1] += p[1], s[2] += p[2], s[3] += p[3];
-      }
-    const double den = s[2] + s[3];
-    const double D = den > (double)eps ? den : (double)eps;
-    bce += s[0];
-    dice += 2.0 * s[1] / D;
-    coef[2 * c] = (float)(2.0 / D);
-    coef[2 * c + 1] = den > (double)eps ? (float)(4.0 * s[1] / (D * D)) : 0.f;
+    for (int i = threadIdx.x; i < N * chunks; i += 256) {
+      const int n = i / chunks, k = i - n * chunks;
+      const float* p = partial + (((long)n * C + c) * chunks + k) * 4;
+      s[0] += p[0], s[1] += p[1], s[2] += p[2], s[3] += p[3];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) red[a][threadIdx.x] = s[a];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) red[a][threadIdx.x] += red[a][threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const double den = red[2][0] + red[3][0];
+      const double D = den > (double)eps ? den : (double)eps;
+      bce += red[0][0];
+      dice += 2.0 * red[1][0] / D;
+      coef[2 * c] = (float)(2.0 / D);
+      coef[2 * c + 1] = den > (double)eps ? (float)(4.0 * red[1][0] / (D * D)) : 0.f;
+    }
+    __syncthreads();
   }
-  sb[threadIdx.x] = bce, sd[threadIdx.x] = dice;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double b = 0.0, d = 0.0;
-    for (int i = 0; i < 64; ++i) b += sb[i], d += sd[i];
-    *loss = (float)((double)alpha * (b / count) + (double)beta * (1.0 - d / C));
-  }
+  if (threadIdx.x == 0) *loss = (float)((double)alpha * (bce / count) + (double)beta * (1.0 - dice / C));
 }
 
 __global__ __launch_bounds__(RX_LOSS_BLOCK) void bce_dice_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, long V, int C,
@@ -153,16 +160,16 @@ __global__ __launch_bounds__(RX_LOSS_BLOCK) void masked_cosine_partial_kernel(co
   block_reduce_store<2>(acc, partial + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2);
 }
 
-__global__ __launch_bounds__(64) void masked_cosine_finalize_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ loss,
-                                                                    float* __restrict__ coef) {
-  __shared__ double s0[64], s1[64];
+__global__ __launch_bounds__(256) void masked_cosine_finalize_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ loss,
+                                                                     float* __restrict__ coef) {
+  __shared__ double s0[256], s1[256];
   double a = 0.0, m = 0.0;
-  for (int i = threadIdx.x; i < nblocks; i += 64) a += partial[2 * i], m += partial[2 * i + 1];
+  for (int i = threadIdx.x; i < nblocks; i += 256) a += partial[2 * i], m += partial[2 * i + 1];
   s0[threadIdx.x] = a, s1[threadIdx.x] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
     a = m = 0.0;
-    for (int i = 0; i < 64; ++i) a += s0[i], m += s1[i];
+    for (int i = 0; i < 256; ++i) a += s0[i], m += s1[i];
     *loss = (float)(1.0 - a / (m + 1e-8));
     coef[0] = (float)(1.0 / (m + 1e-8));
   }
@@ -213,7 +220,7 @@ extern "C" int rx_bce_dice_loss_fwd(const float* logits, const float* target, in
   hipStream_t st = (hipStream_t)stream;
   const int chunks = loss_chunks(v);
   hipLaunchKernelGGL(bce_dice_partial_kernel, dim3(chunks, n * c), dim3(RX_LOSS_BLOCK), 0, st, logits, target, v, smoothing, (float*)ws);
-  hipLaunchKernelGGL(bce_dice_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, n, c, chunks, (double)n * c * (double)v, alpha,
+  hipLaunchKernelGGL(bce_dice_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, n, c, chunks, (double)n * c * (double)v, alpha,
                      beta, eps, loss, coef);
   RX_CHECK_LAUNCH("rx_bce_dice_loss_fwd");
   return RX_OK;
@@ -238,7 +245,7 @@ extern "C" int rx_masked_cosine_loss_fwd(const float* pred, const float* target,
   hipStream_t st = (hipStream_t)stream;
   const int chunks = loss_chunks(v);
   hipLaunchKernelGGL(masked_cosine_partial_kernel, dim3(chunks, n), dim3(RX_LOSS_BLOCK), 0, st, pred, target, v, c, (float*)ws);
-  hipLaunchKernelGGL(masked_cosine_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, chunks * n, loss, coef);
+  hipLaunchKernelGGL(masked_cosine_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, chunks * n, loss, coef);
   RX_CHECK_LAUNCH("rx_masked_cosine_loss_fwd");
   return RX_OK;
 }
