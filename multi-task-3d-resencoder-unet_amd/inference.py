@@ -1,0 +1,142 @@
+"""Sliding-window inference with overlap blending, on the device.
+
+Reference: inference.py:115-157 (patch loop: activation, `sum += pred`, `count += 1` per patch), :166-210 (overlap
+processing: targets named "normals" with 3 channels are re-normalised `sum / (|sum| + 1e-8)`, everything else is averaged
+`sum / count`, both only where count > 0), :251-263 (cast: normals `(v+1)/2*65535` -> uint16, others `v*255` -> uint8, clipped),
+patch positions helpers.py:200-216.  The reference streams every patch through zarr chunks on the host (read-modify-write
+per patch) and is broken at HEAD against its own ConfigManager; here the volume, the sum and the count
+accumulators live in HBM for the whole run and only the finished arrays come back.
+
+The forward passes are the HIP engine's eval-mode plans (logits only -- the activation is applied HERE exactly as
+inference.py:121-133 does it from the target's `activation` key, never twice), so a CPU tensor is an error as everywhere
+else in this package.  Accumulation / blending are a handful of torch slice ops on device tensors: plumbing, not kernels.
+"""
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+def generate_positions(min_val: int, max_val: int, patch_size: int, step: int):
+    """start indices of sliding-window patches; the last patch is forced to end at `max_val` (helpers.py:200-216)"""
+    if patch_size > max_val - min_val:
+        raise ValueError(f"patch ({patch_size}) larger than the volume extent ({max_val - min_val})")
+    positions = []
+    pos = min_val
+    while pos + patch_size <= max_val:
+        positions.append(pos)
+        pos += step
+    last = max_val - patch_size
+    if last > positions[-1]:
+        positions.append(last)
+    return sorted(set(positions))
+
+
+def all_positions(shape: Sequence[int], patch: Sequence[int], overlap: float):
+    """(z, y, x) patch origins, z-major; step = patch * (1 - overlap) per axis, at least 1"""
+    axes = []
+    for dim, p in zip(shape, patch):
+        step = max(1, int(round(p * (1.0 - overlap))))
+        axes.append(generate_positions(0, dim, p, step))
+    return [(z, y, x) for z in axes[0] for y in axes[1] for x in axes[2]]
+
+
+class SlidingWindowInferer:
+    """`SlidingWindowInferer(model, targets, patch_size, batch_size, overlap)(volume)` -> dict of arrays.
+
+    model    : NetworkFromConfig (HIP engine); put into eval mode here.
+    targets  : mapping name -> {"channels": c, "activation": "sigmoid" | "softmax" | "none"}  (inference.py:121-133);
+               defaults to the model's own task table.
+    volume   : (C, Z, Y, X) or (Z, Y, X) float array / tensor, host or device.
+    returns  : {name: float32 (c, Z, Y, X) blended prediction, name + "_final": uint8 / uint16 cast (reference dtype rule)}
+    """
+
+    def __init__(self, model, targets: Optional[dict] = None, patch_size: Optional[Sequence[int]] = None, batch_size: int = 2,
+                 overlap: float = 0.5, compute_dtype: Optional[torch.dtype] = torch.bfloat16, device="cuda"):
+        self.model = model
+        self.targets = dict(targets if targets is not None else model.tasks)
+        self.patch = tuple(patch_size if patch_size is not None else model.patch_size)
+        if len(self.patch) != 3:
+            raise ValueError("sliding-window inference is implemented for 3-D patches")
+        self.batch_size = int(batch_size)
+        self.overlap = float(overlap)
+        self.compute_dtype = compute_dtype
+        self.device = torch.device(device)
+
+    @staticmethod
+    def _activate(logits, kind):
+        kind = (kind or "none").lower()
+        if kind == "sigmoid":
+            return torch.sigmoid(logits)
+        if kind == "softmax":
+            return torch.softmax(logits, dim=1)
+        return logits
+
+    @torch.no_grad()
+    def accumulate(self, volume) -> Tuple[Dict[str, torch.Tensor], torch.Tensor]:
+        """the patch loop (inference.py:115-157): returns ({name: sum (c,Z,Y,X)}, count (Z,Y,X)) on the device"""
+        vol = torch.as_tensor(volume)
+        if vol.dim() == 3:
+            vol = vol.unsqueeze(0)
+        vol = vol.to(self.device, torch.float32)
+        _, Z, Y, X = vol.shape
+        pz, py, px = self.patch
+        pos = all_positions((Z, Y, X), self.patch, self.overlap)
+        sums = {n: torch.zeros((int(t["channels"]), Z, Y, X), dtype=torch.float32, device=self.device) for n, t in self.targets.items()}
+        count = torch.zeros((Z, Y, X), dtype=torch.float32, device=self.device)
+        was_training = self.model.training
+        self.model.train()          # logits out of the engine; the activation is applied below, once (inference.py:121-133)
+        prev_dtype = getattr(self.model, "compute_dtype", None)
+        if self.compute_dtype is not None:
+            self.model.compute_dtype = self.compute_dtype
+        try:
+            for i in range(0, len(pos), self.batch_size):
+                chunk = pos[i:i + self.batch_size]
+                while len(chunk) < self.batch_size and i > 0:      # keep ONE plan shape: pad the last batch with a repeat
+                    chunk = chunk + [chunk[-1]]
+                patches = torch.stack([vol[:, z:z + pz, y:y + py, x:x + px] for z, y, x in chunk]).contiguous()
+                raw = self.model(patches)
+                valid = min(self.batch_size, len(pos) - i)
+                for name, t in self.targets.items():
+                    pred = self._activate(raw[name].float(), t.get("activation", "none"))
+                    for b in range(valid):
+                        z, y, x = chunk[b]
+                        sums[name][:, z:z + pz, y:y + py, x:x + px] += pred[b]
+                for b in range(valid):
+                    z, y, x = chunk[b]
+                    count[z:z + pz, y:y + py, x:x + px] += 1.0
+        finally:
+            self.model.compute_dtype = prev_dtype
+            self.model.train(was_training)
+        return sums, count
+
+    @staticmethod
+    def blend(name: str, sum_t: torch.Tensor, count: torch.Tensor) -> torch.Tensor:
+        """overlap processing (inference.py:166-210)"""
+        mask = count > 0
+        out = sum_t.clone()
+        if name.lower() == "normals":
+            if sum_t.shape[0] == 3:
+                mag = torch.sqrt((sum_t * sum_t).sum(0)) + 1e-8
+                out = torch.where(mask, sum_t / mag, sum_t)
+            return out
+        return torch.where(mask, sum_t / count.clamp(min=1.0), sum_t)
+
+    @staticmethod
+    def cast_final(name: str, blended: torch.Tensor) -> torch.Tensor:
+        """float32 -> uint16 (normals, [-1,1] -> [0,65535]) or uint8 ([0,1] -> [0,255]), truncating like astype (inference.py:251-263)"""
+        if name.lower() == "normals":
+            v = ((blended + 1.0) / 2.0 * 65535.0).clamp(0, 65535)
+            return v.to(torch.int32).to(torch.uint16) if hasattr(torch, "uint16") else v.to(torch.int32)
+        return (blended * 255.0).clamp(0, 255).to(torch.uint8)
+
+    @torch.no_grad()
+    def __call__(self, volume) -> Dict[str, np.ndarray]:
+        sums, count = self.accumulate(volume)
+        out = {}
+        for name, s in sums.items():
+            b = self.blend(name, s, count)
+            out[name] = b.cpu().numpy()
+            f = self.cast_final(name, b)
+            out[name + "_final"] = f.cpu().numpy() if f.dtype != torch.int32 else f.cpu().numpy().astype(np.uint16)
+        return out

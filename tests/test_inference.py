@@ -1,0 +1,95 @@
+"""Sliding-window inference (**parity unpinned**, see oracle/inference_oracle.py).
+
+CPU: the position rule (helpers.py:200-216) against hand-derived answers and the oracle restatement; blending / cast
+arithmetic of the product against the numpy oracle on synthetic sums.
+GPU: the whole pipeline (HIP engine forwards, device accumulators) against the numpy oracle driven by the CPU oracle
+network with identical weights -- fp32 compute mode, tolerance 2e-4 on the blended floats, +-1 on the integer casts."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import inference_oracle as ioracle   # noqa: E402
+import resenc_oracle as oracle      # noqa: E402
+
+
+def _product():
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd import inference
+    return inference
+
+
+def test_positions_known_answers():
+    inf = _product()
+    assert inf.generate_positions(0, 64, 16, 8) == [0, 8, 16, 24, 32, 40, 48]
+    assert inf.generate_positions(0, 50, 16, 8) == [0, 8, 16, 24, 32, 34]          # last patch forced to end at 50
+    assert inf.generate_positions(0, 16, 16, 8) == [0]
+    assert inf.generate_positions(3, 100, 32, 20) == [3, 23, 43, 63, 68]
+    for args in [(0, 41, 14, 7), (0, 129, 128, 64), (0, 200, 64, 48), (5, 77, 9, 4)]:
+        assert inf.generate_positions(*args) == ioracle.generate_positions(*args)
+    with pytest.raises(ValueError):
+        inf.generate_positions(0, 10, 16, 8)
+    pos = inf.all_positions((20, 16, 24), (16, 16, 16), 0.5)
+    assert pos == [(z, 0, x) for z in (0, 4) for x in (0, 8)]
+
+
+def test_blend_and_cast_match_oracle():
+    inf = _product().SlidingWindowInferer
+    rng = np.random.default_rng(0)
+    cnt = rng.integers(0, 4, size=(6, 7, 8)).astype(np.float32)
+    seg = rng.random((1, 6, 7, 8)).astype(np.float32) * cnt            # sums of probabilities
+    nrm = rng.normal(size=(3, 6, 7, 8)).astype(np.float32) * cnt
+    targets = {"sheet": {"channels": 1}, "normals": {"channels": 3}}
+    for name, s in (("sheet", seg), ("normals", nrm)):
+        b = inf.blend(name, torch.from_numpy(s), torch.from_numpy(cnt)).numpy()
+        ref = s.copy()
+        mask = cnt > 0
+        if name == "normals":
+            mag = np.sqrt((ref ** 2).sum(0)) + 1e-8
+            for k in range(3):
+                ref[k][mask] /= mag[mask]
+            fin_ref = np.clip((ref + 1.0) / 2.0 * 65535.0, 0, 65535).astype(np.uint16)
+        else:
+            ref[..., mask] /= cnt[mask]
+            fin_ref = np.clip(ref * 255.0, 0, 255).astype(np.uint8)
+        assert np.allclose(b, ref, rtol=1e-6, atol=1e-7), name
+        fin = inf.cast_final(name, torch.from_numpy(ref)).numpy().astype(fin_ref.dtype)
+        assert np.array_equal(fin, fin_ref), name
+    assert targets
+
+
+@pytest.mark.gpu
+def test_pipeline_matches_oracle_on_the_device():
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
+    from mt3d_amd.engine import lib
+    lib.require_device()
+    inf = _product()
+    tasks = {"sheet": {"channels": 1, "activation": "sigmoid"}, "normals": {"channels": 3, "activation": "none"}}
+    mgr = oracle.make_mgr((16, 16, 16), tasks, 1, 2, True, {})
+    torch.manual_seed(3)
+    ref_net = oracle.NetworkFromConfig(mgr).eval()
+    torch.manual_seed(3)
+    net = NetworkFromConfig(mgr).cuda()
+    g = torch.Generator().manual_seed(5)
+    vol = torch.rand((1, 20, 28, 36), generator=g)
+    runner = inf.SlidingWindowInferer(net, tasks, (16, 16, 16), batch_size=2, overlap=0.5, compute_dtype=torch.float32)
+    got = runner(vol)
+    pos = inf.all_positions(vol.shape[1:], (16, 16, 16), 0.5)
+
+    def predict(patches):
+        with torch.no_grad():
+            ref_net.train()          # logits (the activation is the inference loop's job)
+            out = ref_net(torch.from_numpy(patches))
+        return {k: v.numpy() for k, v in out.items()}
+    blended, final = ioracle.sliding_window(vol.numpy(), predict, tasks, (16, 16, 16), 2, pos)
+    for name in tasks:
+        assert got[name].shape == blended[name].shape
+        err = np.abs(got[name] - blended[name]).max()
+        assert err < 2e-4, (name, err)
+        d = np.abs(got[name + "_final"].astype(np.int64) - final[name].astype(np.int64)).max()
+        assert d <= 1, (name, d)
+    assert got["sheet_final"].dtype == np.uint8 and got["normals_final"].dtype == np.uint16
