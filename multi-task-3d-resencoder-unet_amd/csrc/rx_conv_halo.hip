@@ -359,6 +359,197 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent, weight-stationary, wave-specialised variant for the 32 -> 32 channel layers at full resolution (16-bit
+// types: one 64-byte channel chunk).  Ablation of conv_halo32 on 32->32 @128^3 (366 us): without MFMAs 224 us -- per
+// 256-voxel tile a workgroup re-stages ALL 27x32x32 weights (55 KB) next to a 41 KB halo for only 108 MFMAs per wave.
+// Here a workgroup keeps the weights in LDS for its whole life and walks a contiguous range of tiles:
+//   LDS = 27x32 weight rows (55,296 B) + TWO halo buffers of 648 x 80 B (103,680 B) = 158,976 B -> one workgroup per CU,
+//   512 threads = 4 consumer waves (MFMA loop of conv_halo32 + epilogue stores) and 4 producer waves (halo of the NEXT
+//   tile: global -> registers -> LDS), one barrier per tile.
+// ---------------------------------------------------------------------------------------------------------------------
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. makes every wave wait for the
+// write acknowledgements of its epilogue stores (ablation: 1.3 us per tile) although nobody in the kernel reads them
+__device__ inline void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#define CH32P_HALO_BYTES (648 * 80)
+#define CH32P_W_BYTES (27 * 32 * 64)
+
+template <typename T>
+__global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
+                                                              T* __restrict__ out, const ConvHaloGeom g, int tiles_per_wg) {
+  constexpr int P = Elem<T>::PER16;
+  constexpr int TZ = 4, TY = 4, TX = 16, HY = TY + 2, HX = TX + 2, HV = 648;
+  constexpr int ROWB = 80;
+  constexpr int XPIECES = (HV * 4 + 255) / 256;  // 11 (256 producer threads)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sW = smem;                            // [27][32][64 B], chunk XOR (row>>2)&3
+  unsigned char* sX0 = smem + CH32P_W_BYTES;           // two halo buffers [HV][80 B]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(g.NT, t_begin + tiles_per_wg);
+
+  // ---- weights: once per workgroup (all 512 threads)
+  for (int i = tid; i < 27 * 32 * 4; i += 512) {
+    const int c4 = i & 3, rr = i >> 2;                 // rr = tap*32 + co
+    const u32x4 v = *reinterpret_cast<const u32x4*>(w + (long)rr * g.Ci + c4 * P);
+    *reinterpret_cast<u32x4*>(sW + rr * 64 + ((c4 ^ ((rr >> 2) & 3)) << 4)) = v;
+  }
+
+  auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0) {
+    const int tx = tile % g.tx_n, t1 = tile / g.tx_n;
+    const int ty = t1 % g.ty_n, t2 = t1 / g.ty_n;
+    const int tz = t2 % g.tz_n;
+    n = t2 / g.tz_n;
+    z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+  };
+
+  if (wave >= 4) {
+    // ================================= producers =================================
+    const int ptid = tid - 256, chunk = ptid & 3;
+    int xh[XPIECES];
+#pragma unroll
+    for (int p = 0; p < XPIECES; ++p) {
+      const int row = (ptid >> 2) + 64 * p;
+      const int hx = row % HX, t = row / HX;
+      xh[p] = row < HV ? ((t / HY) << 16) | ((t % HY) << 8) | hx : -1;
+    }
+    u32x4 xr[XPIECES];
+    auto load_halo = [&](int tile) {
+      int n, z0, y0, x0;
+      tile_origin(tile, n, z0, y0, x0);
+      const T* in_n = in + (long)n * g.in_ss + chunk * P;
+#pragma unroll
+      for (int p = 0; p < XPIECES; ++p) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (xh[p] >= 0) {
+          const int z = z0 + (xh[p] >> 16) - 1, y = y0 + ((xh[p] >> 8) & 255) - 1, x = x0 + (xh[p] & 255) - 1;
+          if ((unsigned)z < (unsigned)g.Z && (unsigned)y < (unsigned)g.Y && (unsigned)x < (unsigned)g.X && !(g.dbg & 1))
+            v = *reinterpret_cast<const u32x4*>(in_n + ((long)(z * g.Y + y) * g.X + x) * g.ldi);
+        }
+        xr[p] = v;
+      }
+    };
+    auto commit = [&](int buf) {
+      unsigned char* sX = sX0 + buf * CH32P_HALO_BYTES;
+#pragma unroll
+      for (int p = 0; p < XPIECES; ++p) {
+        const int row = (ptid >> 2) + 64 * p;
+        if (xh[p] >= 0) *reinterpret_cast<u32x4*>(sX + row * ROWB + chunk * 16) = xr[p];
+      }
+    };
+    if (t_begin < t_end) {
+      load_halo(t_begin);
+      commit(0);
+      if (t_begin + 1 < t_end) load_halo(t_begin + 1);
+    }
+    __syncthreads();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const int buf = (tile - t_begin) & 1;
+      if (tile + 1 < t_end) {
+        commit(buf ^ 1);
+        if (tile + 2 < t_end) load_halo(tile + 2);
+      }
+      lds_only_barrier();
+    }
+  } else {
+    // ================================= consumers =================================
+    const int fr = lane & 31, fh = lane >> 5;
+    const int fv = lane_voxel(fr);
+    int xoffb[2];                                       // byte offset of this lane's voxel centre inside a halo buffer
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int v = (wave * 2 + b) * 32 + fv;
+      const int vx = v & 15, vy = (v >> 4) & 3, vz = v >> 6;
+      xoffb[b] = (((vz + 1) * HY + (vy + 1)) * HX + vx + 1) * ROWB + fh * 16;
+    }
+    const int wsw = (fr >> 2) & 3;
+    const unsigned char* wb0 = sW + fr * 64 + (((0 + fh) ^ wsw) << 4);
+    const unsigned char* wb1 = sW + fr * 64 + (((2 + fh) ^ wsw) << 4);
+    const int sgn = g.flip ? -1 : 1;
+    __syncthreads();                                    // weights + tile 0
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const int buf = (tile - t_begin) & 1;
+      const unsigned char* sX = sX0 + buf * CH32P_HALO_BYTES;
+      f32x16 acc[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+      if (!(g.dbg & 4))
+#pragma unroll
+      for (int dzg = 0; dzg < 3; ++dzg) {
+        const int dzoff = sgn * (dzg - 1) * (HY * HX * ROWB);
+        const unsigned char* x0p = sX + xoffb[0] + dzoff;
+        const unsigned char* x1p = sX + xoffb[1] + dzoff;
+        const unsigned char* w0 = wb0 + dzg * 9 * 32 * 64;
+        const unsigned char* w1 = wb1 + dzg * 9 * 32 * 64;
+        // one consumer wave per SIMD: nobody else hides the LDS latency, so fragments are read DEPTH steps (2*DEPTH MFMAs)
+        // ahead into a rolling ring of register slots, pinned with sched_barrier
+        constexpr int DEPTH = 3;
+        u32x4 fa[DEPTH + 1], f0[DEPTH + 1], f1[DEPTH + 1];
+        auto ld = [&](int i, int slot) {
+          const int tl = i >> 1, ks = i & 1;
+          const int toff = sgn * ((tl / 3 - 1) * HX + (tl % 3 - 1)) * ROWB;
+          fa[slot] = *reinterpret_cast<const u32x4*>((ks ? w1 : w0) + tl * 32 * 64);
+          f0[slot] = *reinterpret_cast<const u32x4*>(x0p + toff + ks * 32);
+          f1[slot] = *reinterpret_cast<const u32x4*>(x1p + toff + ks * 32);
+        };
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) ld(i, i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+          if (i + DEPTH < 18) ld(i + DEPTH, (i + DEPTH) % (DEPTH + 1));
+          __builtin_amdgcn_sched_barrier(0);
+          Mma<T>::run(acc[0], fa[i % (DEPTH + 1)], f0[i % (DEPTH + 1)]);
+          Mma<T>::run(acc[1], fa[i % (DEPTH + 1)], f1[i % (DEPTH + 1)]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // ---- epilogue of this tile
+      int n, z0, y0, x0;
+      tile_origin(tile, n, z0, y0, x0);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int v = (wave * 2 + b) * 32 + fv;
+        const int z = z0 + (v >> 6), y = y0 + ((v >> 4) & 3), x = x0 + (v & 15);
+        if (z >= g.Z || y >= g.Y || x >= g.X || (g.dbg & 8)) continue;
+        T* op = out + (long)n * g.out_ss + ((long)(z * g.Y + y) * g.X + x) * g.ldo;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int co = 8 * g4 + 4 * fh;
+          T vals[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float f = acc[b][4 * g4 + i];
+            if (bias) f += bias[co + i];
+            if (g.accumulate) f += Elem<T>::to_f(op[co + i]);
+            vals[i] = Elem<T>::from_f(f);
+          }
+          *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
+        }
+      }
+      lds_only_barrier();      // the stores of this tile stay in flight under the next tile's MFMAs
+    }
+  }
+}
+
+template <typename T>
+static void ch32p_launch(hipStream_t st, const void* in, const void* w, const float* bias, void* out, const ConvHaloGeom& g) {
+  const size_t lds = (size_t)CH32P_W_BYTES + 2 * (size_t)CH32P_HALO_BYTES;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32p_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  int wgs = g.NT < 256 ? g.NT : 256;                    // one persistent workgroup per CU
+  const int per = (g.NT + wgs - 1) / wgs;
+  wgs = (g.NT + per - 1) / per;
+  hipLaunchKernelGGL((conv_halo32p_kernel<T>), dim3(wgs), dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
+}
+
 template <typename T>
 static void ch32_launch(dim3 grid, hipStream_t st, const void* in, const void* w, const float* bias, void* out, const ConvHaloGeom& g) {
   const size_t lds = (size_t)648 * 80 + (size_t)9 * 32 * 64;
@@ -447,6 +638,19 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   if (BN == 64 && (long)g.NT * (g.Co / 64) < 256) BN = 32;  // under-filled grid: twice the workgroups, half the work each
   if ((long)g.NT * (g.Co / BN) < 128) return 0;  // too few workgroups: the split-K gather kernel fills the chip better
   dim3 grid(g.NT, g.Co / BN);
+  if (BN == 32 && TZ == 4 && TY == 4 && TX == 16 && dt != RX_F32 && g.Ci == 32 && g.Co == 32 && g.NT >= 512 && !getenv("RX_NO_CH32P")) {
+    rx_note_kernel("conv_halo32p_kernel");               // 32 -> 32 channels: persistent, weights stationary in LDS
+    if (dt == RX_BF16)
+      ch32p_launch<bf16_t>(st, in->ptr, w, bias, out->ptr, g);
+    else
+      ch32p_launch<f16_t>(st, in->ptr, w, bias, out->ptr, g);
+    hipError_t e4 = hipGetLastError();
+    if (e4 != hipSuccess) {
+      rx_set_error("conv_halo32p: %s", hipGetErrorString(e4));
+      return RX_ELAUNCH;
+    }
+    return 1;
+  }
   if (BN == 32 && TZ == 4 && TY == 4 && TX == 16) {  // full-resolution layers: compile-time tile, padded rows
     rx_note_kernel("conv_halo32_kernel");
     switch (dt) {
