@@ -169,6 +169,7 @@ class NetworkFromConfig(nn.Module):
         cd = model_config.get("compute_dtype", None)
         self.compute_dtype = _DTYPES[cd] if isinstance(cd, str) else cd   # None -> follow autocast
         self._plans = {}
+        self._weights_epoch = 0     # advanced by every backward: fused optimizers do not bump Tensor._version (engine/plan.py)
         if getattr(mgr, "verbose", False):
             print(f"--- NetworkFromConfig (rxunet HIP engine): stages={self.num_stages} "
                   f"features={self.features_per_stage} blocks={self.n_blocks_per_stage} strides={self.strides} "

@@ -32,6 +32,20 @@ class UnsupportedConfig(NotImplementedError):
     pass
 
 
+_SIDE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
+
+
+def side_stream(device):
+    """ONE side HIP stream per device, shared by every plan: weight gradients, weight packing and the streamed optimizer
+    step are FIFO-ordered against each other across plans (a training plan's parameter update vs. an evaluation plan's
+    re-pack of the same parameters)."""
+    key = str(device)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class _NullCtx:
     def __enter__(self):
         return self
@@ -116,6 +130,7 @@ class Plan:
         self._ws2 = None
         self._dy_turn: Dict[tuple, int] = {}
         self._dy_free: Dict[int, "torch.cuda.Event"] = {}
+        self.raw_param_event = None           # set by engine/streamed_step.py: parameters the kernels read raw are updated
         # HIP graphs (opt-in: RX_GRAPHS=1 or plan.use_graphs = True): the forward / backward launch lists are static
         # (fixed buffers, fixed shapes), so after two eager passes (lazy allocations, kernel attribute calls) each list
         # is captured once -- side stream, events and weight packing included -- and every later step is a single
@@ -570,18 +585,28 @@ class Plan:
         """re-pack every parameter whose version moved (all of them with `force`: inside a captured graph).  The packs are pure HBM traffic (1.3 GB at cfg2) while the
         first stages of the forward pass are MFMA/LDS bound: they run on the side stream in first-use order and each
         consumer conv waits for its own parameter's event."""
+        # Staleness: tensor version / address AND the model's weight epoch.  torch's FUSED optimizers (fused=True
+        # Adam/AdamW/SGD: `_fused_adamw_` ...) update parameters WITHOUT bumping `Tensor._version`, so a version check alone
+        # would keep the initial packed weights for a whole training run.  Every backward pass through the engine
+        # therefore starts a new weight epoch (an optimizer step is what normally follows it) and all plans of the model
+        # re-pack on their next forward; pure inference (no backward) keeps its packs.
+        epoch = getattr(self.net, "_weights_epoch", 0)
         stale = [e for e in self.packs
-                 if force or not (e["version"] == e["param"]._version and e.get("ptr") == e["param"].data_ptr())]
+                 if force or e.get("epoch") != epoch
+                 or not (e["version"] == e["param"]._version and e.get("ptr") == e["param"].data_ptr())]
         if not stale:
             return
         side = None
         if self.device.type == "cuda" and self.overlap_wgrad:
             if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
+                self._side = side_stream(self.device)
                 self._ws2 = torch.empty(ops.workspace().numel(), dtype=torch.uint8, device=self.device)
             side = self._side
             side.wait_stream(torch.cuda.current_stream())      # the optimizer's writes are on the main stream
-        for ent in stale:
+        self._pack_entries(stale, side)
+
+    def _pack_entries(self, entries, side):
+        for ent in entries:
             p = ent["param"]
             w = p.detach()
             if w.dtype != torch.float32 or not w.is_contiguous():
@@ -600,6 +625,12 @@ class Plan:
                     ent["event"] = ev
             ent["version"] = p._version
             ent["ptr"] = p.data_ptr()
+            ent["epoch"] = getattr(self.net, "_weights_epoch", 0)
+
+    def repack(self, entries):
+        """re-pack `entries` on the side stream NOW (called from inside a `torch.cuda.stream(side)` block by the streamed
+        optimizer step, right after the update of those parameters) and mark them fresh"""
+        self._pack_entries(entries, self._side)
 
     # ---- HIP graph plumbing ---------------------------------------------------------------------------------
     def _graphs_on(self):
@@ -635,6 +666,9 @@ class Plan:
         return st
 
     def _forward_body(self, force_packs):
+        if self.raw_param_event is not None:      # stem / bias / head parameters are read raw by the kernels
+            torch.cuda.current_stream().wait_event(self.raw_param_event)
+            self.raw_param_event = None
         self.refresh_packs(force=force_packs)
         for step in self.fwd:
             step()
@@ -660,6 +694,7 @@ class Plan:
             if not st["eager"]:                       # the graph re-packed every parameter
                 for ent in self.packs:
                     ent["version"], ent["ptr"], ent["event"] = ent["param"]._version, ent["param"].data_ptr(), None
+                    ent["epoch"] = getattr(self.net, "_weights_epoch", 0)
         else:
             self._x = x.unsqueeze(2) if self.two_d else x
             self._forward_body(force_packs=False)
@@ -701,8 +736,10 @@ class Plan:
                 g = buf
             self._dlogits[k] = g.unsqueeze(2) if self.two_d else g
         if self.overlap_wgrad and self._side is None and self.device.type == "cuda":
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = side_stream(self.device)
             self._ws2 = torch.empty(ops.workspace().numel(), dtype=torch.uint8, device=self.device)
+        # a backward is what an optimizer step follows: new weight epoch for every plan of this model (see refresh_packs)
+        self.net._weights_epoch = getattr(self.net, "_weights_epoch", 0) + 1
         if not graphs:
             return self._backward_body()
         key = ("b", tuple(sorted(self._dlogits)))

@@ -195,3 +195,86 @@ def test_hip_graph_replay_is_bit_identical_to_eager(NetworkFromConfig):
     assert l_e == l_g
     for n in p_e:
         assert torch.equal(p_e[n], p_g[n]), n
+
+
+def test_streamed_optimizer_step_is_bit_identical(NetworkFromConfig):
+    """engine/streamed_step.py: the fused AdamW update runs on the side stream in forward order, chunk by chunk, each chunk
+    followed by the re-pack of its parameters; the next forward waits per parameter.  Same per-tensor arithmetic ->
+    parameters (and losses) after 6 steps must equal the plain `optimizer.step()` run bit for bit; an evaluation forward
+    (a different plan of the same module) in between must see the updated weights."""
+    from mt3d_amd.engine.streamed_step import StreamedOptimizerStep
+    c = CASES["auto16_2head"]
+
+    def run(streamed):
+        net, _, _ = build(NetworkFromConfig, "auto16_2head")
+        x, targets = oracle.synthetic_batch(c["batch"], c["in_channels"], c["patch"], c["tasks"], 7)
+        x = x.cuda()
+        targets = {k: v.cuda() for k, v in targets.items()}
+        params = [p for p in net.parameters()]
+        opt = torch.optim.AdamW(params, lr=1e-2, weight_decay=0.01, fused=True)
+        stepper = StreamedOptimizerStep(opt, net, chunk_bytes=1 << 16) if streamed else None     # many chunks
+        losses, evals = [], []
+        for step in range(6):
+            net.train()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = net(x)
+            loss = oracle.train_loss(out, targets, c["tasks"])
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, 3)
+            if streamed:
+                stepper.step()
+            else:
+                opt.step()
+            opt.zero_grad(set_to_none=True)
+            losses.append(loss.item())
+            if step in (2, 4):
+                net.eval()
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                    evals.append({k: v.clone() for k, v in net(x).items()})
+        if streamed:
+            stepper.synchronize()
+        torch.cuda.synchronize()
+        return losses, evals, {n: p.detach().clone() for n, p in net.named_parameters()}
+
+    l_a, e_a, p_a = run(False)
+    l_b, e_b, p_b = run(True)
+    assert l_a == l_b
+    for a, b in zip(e_a, e_b):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    for n in p_a:
+        assert torch.equal(p_a[n], p_b[n]), n
+
+
+@pytest.mark.parametrize("opt_kind", ["adamw_fused", "adamw_foreach", "sgd_fused"])
+def test_training_plan_sees_optimizer_updates(NetworkFromConfig, opt_kind):
+    """torch's FUSED optimizers update parameters without bumping Tensor._version: the packed weight copies of the
+    training plan must still be refreshed after every step.  After 3 optimizer steps the training plan's forward must
+    equal (bit for bit) the forward of a FRESH module loaded with the same state_dict."""
+    net, c, _ = build(NetworkFromConfig, "auto16_2head")
+    x, targets = oracle.synthetic_batch(c["batch"], c["in_channels"], c["patch"], c["tasks"], 7)
+    x = x.cuda()
+    targets = {k: v.cuda() for k, v in targets.items()}
+    params = [p for p in net.parameters()]
+    opt = {"adamw_fused": lambda: torch.optim.AdamW(params, lr=1e-2, fused=True),
+           "adamw_foreach": lambda: torch.optim.AdamW(params, lr=1e-2, foreach=True),
+           "sgd_fused": lambda: torch.optim.SGD(params, lr=0.05, momentum=0.9, fused=True)}[opt_kind]()
+
+    def fwd(m):
+        m.train()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return m(x)
+    first = None
+    for _ in range(3):
+        out = fwd(net)
+        first = first if first is not None else {k: v.detach().clone() for k, v in out.items()}
+        oracle.train_loss(out, targets, c["tasks"]).backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    out = fwd(net)
+    fresh, _, _ = build(NetworkFromConfig, "auto16_2head")
+    fresh.load_state_dict(net.state_dict())
+    ref = fwd(fresh)
+    for k in out:
+        assert torch.equal(out[k], ref[k]), k
+        assert not torch.equal(out[k], first[k]), "the weights never moved"
