@@ -1226,15 +1226,18 @@ extern "C" int rx_stem_conv_bwd_weight(rx_dtype dt, const float* x_ncdhw, int n,
 template <typename T>
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, int A, int B, int TT, T* __restrict__ same, int flip_same,
                                                    T* __restrict__ swp, int flip_swap) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];  // [32 a][32*TT + 1]
+  // the tile is converted on load and held in the COMPUTE dtype (32 x 864 x 2 B = 55 KB instead of 110 KB: two to three
+  // workgroups per CU instead of one; this pass runs every training step on the side stream, 1.7 GB of traffic at cfg2)
+  extern __shared__ __attribute__((aligned(16))) unsigned char pack_smem[];
+  T* tile = reinterpret_cast<T*>(pack_smem);            // [32 a][32*TT + 2]
   const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
   const int rowlen = 32 * TT;
-  const int pitch = rowlen + 1;
+  const int pitch = rowlen + 2;                          // odd number of dwords per row
   for (int i = threadIdx.x; i < 32 * rowlen; i += 256) {
     int a = i / rowlen, r = i - a * rowlen;  // r = b*TT + t
     float v = 0.f;
     if (a0 + a < A && b0 + r / TT < B) v = w[((size_t)(a0 + a) * B + b0) * TT + r];
-    tile[a * pitch + r] = v;
+    tile[a * pitch + r] = Elem<T>::from_f(v);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < TT * 32 * 32; i += 256) {
@@ -1243,14 +1246,14 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
       int a = r >> 5, b = r & 31;  // b fastest -> contiguous in same[t][a][b]
       if (same && a0 + a < A && b0 + b < B) {
         int to = flip_same ? TT - 1 - t : t;
-        same[((size_t)to * A + a0 + a) * B + b0 + b] = Elem<T>::from_f(tile[a * pitch + b * TT + t]);
+        same[((size_t)to * A + a0 + a) * B + b0 + b] = tile[a * pitch + b * TT + t];
       }
     }
     {
       int b = r >> 5, a = r & 31;  // a fastest -> contiguous in swap[t][b][a]
       if (swp && a0 + a < A && b0 + b < B) {
         int to = flip_swap ? TT - 1 - t : t;
-        swp[((size_t)to * B + b0 + b) * A + a0 + a] = Elem<T>::from_f(tile[a * pitch + b * TT + t]);
+        swp[((size_t)to * B + b0 + b) * A + a0 + a] = tile[a * pitch + b * TT + t];
       }
     }
   }
@@ -1261,7 +1264,7 @@ static int pack_generic(rx_dtype dt, const float* w, int A, int B, int TT, void*
   if (!w || A < 1 || B < 1 || TT < 1 || TT > 27) RX_FAIL(RX_EINVAL, "rx_pack: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   RX_DISPATCH_DTYPE(dt, T, {
-    size_t lds = (size_t)32 * (32 * TT + 1) * sizeof(float);
+    size_t lds = (size_t)32 * (32 * TT + 2) * sizeof(T);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((pack_kernel<T>), dim3((B + 31) / 32, (A + 31) / 32), dim3(256), lds, st, w, A, B, TT, (T*)same, flip_same, (T*)swp,
                        flip_swap);

@@ -130,7 +130,7 @@ class Plan:
         self._ws2 = None
         self._dy_turn: Dict[tuple, int] = {}
         self._dy_free: Dict[int, "torch.cuda.Event"] = {}
-        self.raw_param_event = None           # set by engine/streamed_step.py: parameters the kernels read raw are updated
+        self._raw_seen = None                 # last `net._raw_param_event` (engine/streamed_step.py) this plan waited for
         # HIP graphs (opt-in: RX_GRAPHS=1 or plan.use_graphs = True): the forward / backward launch lists are static
         # (fixed buffers, fixed shapes), so after two eager passes (lazy allocations, kernel attribute calls) each list
         # is captured once -- side stream, events and weight packing included -- and every later step is a single
@@ -666,9 +666,10 @@ class Plan:
         return st
 
     def _forward_body(self, force_packs):
-        if self.raw_param_event is not None:      # stem / bias / head parameters are read raw by the kernels
-            torch.cuda.current_stream().wait_event(self.raw_param_event)
-            self.raw_param_event = None
+        ev = getattr(self.net, "_raw_param_event", None)   # stem / bias / head parameters are read raw by the kernels:
+        if ev is not None and ev is not self._raw_seen:     # a streamed optimizer step updates them on the side stream
+            torch.cuda.current_stream().wait_event(ev)
+            self._raw_seen = ev
         self.refresh_packs(force=force_packs)
         for step in self.fwd:
             step()

@@ -85,7 +85,7 @@ class StreamedOptimizerStep:
             self._adam(raw, group_of)
             ev0 = torch.cuda.Event()
             ev0.record(side)
-            plan.raw_param_event = ev0
+            self.model._raw_param_event = ev0             # every plan of the model waits for it once (Plan._forward_body)
             for chunk in chunks:
                 self._adam(chunk, group_of)
                 plan.repack([packed[id(p)] for p in chunk])

@@ -29,6 +29,7 @@ from .builders.build_network_from_config import NetworkFromConfig
 from .configuration.config_manager import ConfigManager
 from .dataloading.dataset import SyntheticPatchDataset, ZarrSegmentationDataset3D
 from .engine.ddp import GradSync, broadcast_parameters
+from .engine.streamed_step import StreamedOptimizerStep
 from .training.losses.losses import LOSS_FN_MAP
 
 _AMP = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}
@@ -147,6 +148,10 @@ class BaseTrainer:
                 writer = None
         accum = self.mgr.gradient_accumulation
         params = [p for p in model.parameters()]
+        # opt-in (RX_STREAMED_STEP=1): optimizer update + weight re-pack on the engine's side stream, overlapped with the
+        # next forward (falls back to a plain optimizer.step() for anything but a fused Adam/AdamW; never with a GradScaler)
+        stepper = (StreamedOptimizerStep(optimizer, model)
+                   if isinstance(model, NetworkFromConfig) and os.environ.get("RX_STREAMED_STEP", "0") == "1" else None)
 
         def forward_loss(batch, train_mode):
             x = batch["image"].to(device, dtype=torch.float32, non_blocking=True)
@@ -178,13 +183,18 @@ class BaseTrainer:
                 scaler.scale(total / accum).backward()
                 if (i + 1) % accum == 0 or (i + 1) == len(train_loader):
                     torch.nn.utils.clip_grad_norm_(params, 3)
-                    scaler.step(optimizer)
+                    if stepper is not None and not scaler.is_enabled():
+                        stepper.step()
+                    else:
+                        scaler.step(optimizer)
                     scaler.update()
                     optimizer.zero_grad(set_to_none=True)
                 for k, v in per.items():
                     running[k] += float(v)
                 steps += 1
                 patches += bsz
+            if stepper is not None:
+                stepper.synchronize()
             torch.cuda.synchronize(device)
             dt = time.perf_counter() - t0
             self.last_patches_per_sec = patches * self.world / max(dt, 1e-9)
