@@ -16,6 +16,8 @@
 // k-steps of every 64-voxel tile and each computes the whole BR x BC tile; their accumulators are
 // combined through LDS, written as an fp32 slab [split][tap][R][C], and a second kernel sums the
 // slabs in a fixed order (deterministic, no float atomics) and transposes to [R][C][T].
+#include <stdlib.h>
+
 #include "rx_common.h"
 
 
@@ -309,7 +311,8 @@ void rx_wgrad_reduce_launch(const float* slab, int S, int T_, int R, int C, floa
     hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((RC + 255) / 256)), dim3(256), 0, st, slab, S, T_, R, C, dw);
 }
 size_t rx_wgrad_halo_ws_bytes(const rx_act* x, const rx_act* dy);
-int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
+int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, const int32_t stride[3], float* dw, void* ws, size_t ws_bytes,
+                      hipStream_t st);
 
 extern "C" size_t rx_conv3d_bwd_weight_workspace(const rx_act* x, const rx_act* dy, const int32_t kernel[3]) {
   if (!rx_act_ok(x) || !rx_act_ok(dy)) return 0;
@@ -328,8 +331,8 @@ extern "C" int rx_conv3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* 
   if (dy->n != x->n || dy->z != conv_out_dim(x->z, kernel[0], stride[0]) || dy->y != conv_out_dim(x->y, kernel[1], stride[1]) ||
       dy->x != conv_out_dim(x->x, kernel[2], stride[2]))
     RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_weight: geometry mismatch");
-  if (kernel[0] == 3 && kernel[1] == 3 && kernel[2] == 3 && stride[0] == 1 && stride[1] == 1 && stride[2] == 1 && ws && dw) {
-    int rc = rx_wgrad_halo_try(dt, x, dy, dw, ws, ws_bytes, (hipStream_t)stream);  // LDS-halo kernel (16-bit types)
+  if (kernel[0] == 3 && kernel[1] == 3 && kernel[2] == 3 && ws && dw && !(getenv("RX_NO_STRIDED_WGH") && (stride[0] > 1 || stride[1] > 1 || stride[2] > 1))) {
+    int rc = rx_wgrad_halo_try(dt, x, dy, stride, dw, ws, ws_bytes, (hipStream_t)stream);  // LDS-halo kernel (16-bit types), stride 1 or 2
     if (rc < 0) return rc;
     if (rc == 1) return RX_OK;
   }

@@ -28,12 +28,14 @@ struct WgHaloGeom {
   int HY, HX, HV, VT;
   int tz_n, ty_n, tx_n, NT;
   int S, tiles_per_split, panels_c;
+  int sz, sy, sx;        // conv stride per axis (1 or 2); the X halo of a TZ x TY x TX tile of dY is (s*(T-1)+3) per axis
+  int Zi, Yi, Xi;        // extent of X (the conv INPUT); Z, Y, X above are the extent of dY
   int dbg;   // ablation mask (RX_DBG env): 1 stage only the first tile, 2 no MFMA loop
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_h;
 
-#define RX_WGH_MAX_HV 720
+#define RX_WGH_MAX_HV 768
 #define RX_WGH_MAX_VT 256
 #define RX_WGH_XPIECES ((RX_WGH_MAX_HV * 4 + 255) / 256)  // 16-byte pieces of the halo panel per thread
 #define RX_WGH_GPIECES (RX_WGH_MAX_VT * 4 / 256)
@@ -123,9 +125,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const T* __restrict_
     for (int p = 0; p < RX_WGH_XPIECES; ++p) {
       u32x4 val = u32x4{0u, 0u, 0u, 0u};
       if (xh[p] >= 0) {
-        int z = z0 + (xh[p] >> 16) - 1, y = y0 + ((xh[p] >> 8) & 255) - 1, x = x0 + (xh[p] & 255) - 1;
-        if ((unsigned)z < (unsigned)g.Z && (unsigned)y < (unsigned)g.Y && (unsigned)x < (unsigned)g.X)
-          val = *reinterpret_cast<const u32x4*>(xn + ((long)(z * g.Y + y) * g.X + x) * g.ldx + chunk * 8);
+        int z = z0 * g.sz + (xh[p] >> 16) - 1, y = y0 * g.sy + ((xh[p] >> 8) & 255) - 1, x = x0 * g.sx + (xh[p] & 255) - 1;
+        if ((unsigned)z < (unsigned)g.Zi && (unsigned)y < (unsigned)g.Yi && (unsigned)x < (unsigned)g.Xi)
+          val = *reinterpret_cast<const u32x4*>(xn + ((long)(z * g.Yi + y) * g.Xi + x) * g.ldx + chunk * 8);
       }
       xv[p] = val;
     }
@@ -149,14 +151,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const T* __restrict_
     for (int s = 0; s < ksteps; ++s) {
       const int v = 16 * s + 8 * h + q4;
       const int vx = v & (g.TX - 1), vy = (v >> g.lTX) & (g.TY - 1), vz = v >> (g.lTX + g.lTY);
-      const int hr = ((vz + 1) * g.HY + (vy + 1)) * g.HX + vx + 1;  // halo row of voxel v; v+4 is hr+4 (TX >= 8)
+      // halo row of the CENTRE tap of output voxel v (input voxel s*v); v+4 is 4*sx rows further when TX >= 8
+      const int hr = ((vz * g.sz + 1) * g.HY + (vy * g.sy + 1)) * g.HX + vx * g.sx + 1;
       int hr4;
       if (g.TX >= 8)
-        hr4 = hr + 4;
+        hr4 = hr + 4 * g.sx;
       else {  // TX == 4: v+4 is the next x-row
         const int v2 = v + 4;
         const int vy2 = (v2 >> g.lTX) & (g.TY - 1), vz2 = v2 >> (g.lTX + g.lTY);
-        hr4 = ((vz2 + 1) * g.HY + (vy2 + 1)) * g.HX + (v2 & (g.TX - 1)) + 1;
+        hr4 = ((vz2 * g.sz + 1) * g.HY + (vy2 * g.sy + 1)) * g.HX + (v2 & (g.TX - 1)) * g.sx + 1;
       }
       const u32x4 a = tr_frag<T>(sG + v * 32 + coloff, sG + (v + 4) * 32 + coloff);
       const T* b0 = sX + hr * 32 + coloff;
@@ -594,25 +597,31 @@ static int ilog2(int v) {
 }
 
 // returns 1 and fills `g` when the halo kernel applies
-static int wgh_plan(const rx_act* x, const rx_act* dy, WgHaloGeom* g, size_t ws_bytes) {
+static int wgh_plan(const rx_act* x, const rx_act* dy, const int32_t stride[3], WgHaloGeom* g, size_t ws_bytes) {
   memset(g, 0, sizeof(*g));
-  g->N = x->n, g->Z = x->z, g->Y = x->y, g->X = x->x;
+  g->N = dy->n, g->Z = dy->z, g->Y = dy->y, g->X = dy->x;
+  g->Zi = x->z, g->Yi = x->y, g->Xi = x->x;
+  g->sz = stride[0], g->sy = stride[1], g->sx = stride[2];
   g->R = dy->c, g->Cc = x->c, g->ldg = dy->ld, g->ldx = x->ld;
   g->g_ss = rx_act_voxels(dy) * (long)dy->ld;
   g->x_ss = rx_act_voxels(x) * (long)x->ld;
+  const bool strided = stride[0] > 1 || stride[1] > 1 || stride[2] > 1;
   int TX = p2ceil(g->X);
   TX = TX < 4 ? 4 : (TX > 16 ? 16 : TX);
-  int rem = 256 / TX;
+  if (strided && TX > 8) TX = 8;               // the X halo grows with the stride: 64-voxel tiles (2 x 4 x 8) keep it in LDS
+  int budget = strided ? 64 : 256;
+  int rem = budget / TX;
   int TY = p2ceil(g->Y);
-  int capy = TX == 16 ? 4 : 8;
+  int capy = TX == 16 ? 4 : (strided ? 4 : 8);
   if (TY > capy) TY = capy;
   if (TY > rem) TY = rem;
   int TZ = p2ceil(g->Z);
   if (TZ > rem / TY) TZ = rem / TY;
   g->TZ = TZ, g->TY = TY, g->TX = TX, g->lTX = ilog2(TX), g->lTY = ilog2(TY);
   g->VT = TZ * TY * TX;
-  g->HY = TY + 2, g->HX = TX + 2, g->HV = (TZ + 2) * g->HY * g->HX;
-  if (g->VT < 16 || g->VT > RX_WGH_MAX_VT || g->HV > RX_WGH_MAX_HV) return 0;
+  const int HZ = g->sz * (TZ - 1) + 3;
+  g->HY = g->sy * (TY - 1) + 3, g->HX = g->sx * (TX - 1) + 3, g->HV = HZ * g->HY * g->HX;
+  if (g->VT < 16 || g->VT > RX_WGH_MAX_VT || g->HV > RX_WGH_MAX_HV || HZ > 255 || g->HY > 255 || g->HX > 255) return 0;
   g->tz_n = (g->Z + TZ - 1) / TZ, g->ty_n = (g->Y + TY - 1) / TY, g->tx_n = (g->X + TX - 1) / TX;
   g->NT = g->N * g->tz_n * g->ty_n * g->tx_n;
   g->panels_c = g->Cc / 32;
@@ -639,11 +648,12 @@ void rx_wgrad_reduce_launch(const float* slab, int S, int T_, int R, int C, floa
 
 // called by rx_conv3d_bwd_weight; returns 1 if it handled the launch, 0 to fall through to the generic kernel,
 // negative on error
-int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, const int32_t stride[3], float* dw, void* ws, size_t ws_bytes,
+                      hipStream_t st) {
   if (dt == RX_F32) return 0;
   if (x->c % 32 || dy->c % 32 || x->ld % 8 || dy->ld % 8 || ((uintptr_t)x->ptr & 15) || ((uintptr_t)dy->ptr & 15)) return 0;
   WgHaloGeom g;
-  if (!wgh_plan(x, dy, &g, ws_bytes)) return 0;
+  if (!wgh_plan(x, dy, stride, &g, ws_bytes)) return 0;
   const size_t lds = (size_t)(RX_WGH_MAX_VT + RX_WGH_MAX_HV) * 64;
   dim3 grid((g.R / 32) * g.panels_c, g.S);
   {
@@ -654,7 +664,7 @@ int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw,
     }
     g.dbg = dbg;
   }
-  if (g.TZ == 4 && g.TY == 4 && g.TX == 16) {   // compile-time tile
+  if (g.TZ == 4 && g.TY == 4 && g.TX == 16 && g.sz == 1 && g.sy == 1 && g.sx == 1) {   // compile-time tile
     const size_t lds16 = (size_t)WGH16_BUF_BYTES;
     static bool attr16 = false;
     static int ws_mode = 1;
