@@ -626,7 +626,11 @@ static int wgh_plan(const rx_act* x, const rx_act* dy, const int32_t stride[3], 
   g->NT = g->N * g->tz_n * g->ty_n * g->tx_n;
   g->panels_c = g->Cc / 32;
   const long PP = (long)(g->R / 32) * g->panels_c;
-  long S = (512 + PP - 1) / PP;
+  // the wave-specialised 4x4x16 kernel runs ONE workgroup per CU: 256 workgroups are one full wave of the chip (half the
+  // slab traffic and reduce work of 512); the generic kernel runs two per CU
+  long target = (!strided && TZ == 4 && TY == 4 && TX == 16 && !getenv("RX_WGH_S512")) ? 256 : 512;
+  if (target == 256 && g->NT * PP < 16 * 256) target = 512;   // few tiles (16^3 layers): shorter per-workgroup chains win
+  long S = (target + PP - 1) / PP;
   if (PP >= 256) S = 1;  // the panel pairs alone fill the chip: accumulate every tile in registers, write dw directly
   if (S > g->NT) S = g->NT;
   if (S < 1) S = 1;
