@@ -1060,6 +1060,63 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
   }
 }
 
+// One thread per voxel, 32 output channels at a time (16-bit output types): the taps of the voxel are loaded ONCE into
+// registers and every weight comes from LDS as a wave-uniform (broadcast) 16-byte read.  The first version above gave a
+// voxel to 4 threads of 8 channels each: 4x the image loads and bounds checks (428 us for the cfg2 stem; this one is
+// bound by its 864 FMAs per voxel).
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd32_kernel(const float* __restrict__ x, int Cin, int Z, int Y, int X, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, T* __restrict__ out, int ldo, long so, int Co,
+                                                         int kz, int ky, int kx) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [Cin*TT][Co]
+  const int TT = kz * ky * kx;
+  for (int i = threadIdx.x; i < Co * Cin * TT; i += 256) {
+    int co = i / (Cin * TT), r = i - co * (Cin * TT);
+    sw[r * Co + co] = w[i];
+  }
+  __syncthreads();
+  const int n = blockIdx.y;
+  const long V = (long)Z * Y * X;
+  const int pz = (kz - 1) / 2, py = (ky - 1) / 2, px = (kx - 1) / 2;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long)gridDim.x * 256) {
+    const int xx = (int)(v % X), yy = (int)((v / X) % Y), zz = (int)(v / ((long)X * Y));
+    for (int c0 = 0; c0 < Co; c0 += 32) {
+      float acc[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) acc[j] = bias ? bias[c0 + j] : 0.f;
+      for (int ci = 0; ci < Cin; ++ci) {
+        const float* xc = x + ((size_t)n * Cin + ci) * V;
+        for (int a = 0; a < kz; ++a) {
+          const int z2 = zz + a - pz;
+          for (int b = 0; b < ky; ++b) {
+            const int y2 = yy + b - py;
+            for (int c = 0; c < kx; ++c) {
+              const int x2 = xx + c - px;
+              const bool ok = (unsigned)z2 < (unsigned)Z && (unsigned)y2 < (unsigned)Y && (unsigned)x2 < (unsigned)X;
+              const float xv = ok ? xc[((long)z2 * Y + y2) * X + x2] : 0.f;
+              const f32x4* wr = reinterpret_cast<const f32x4*>(sw + ((ci * TT) + (a * ky + b) * kx + c) * Co + c0);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const f32x4 wv = wr[q];           // wave-uniform address: LDS broadcast
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[4 * q + j] += xv * wv[j];
+              }
+            }
+          }
+        }
+      }
+      T* op = out + n * so + v * ldo + c0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        T vals[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vals[j] = Elem<T>::from_f(acc[8 * q + j]);
+        *reinterpret_cast<u32x4*>(op + 8 * q) = *reinterpret_cast<u32x4*>(vals);
+      }
+    }
+  }
+}
+
 static int check_kernel13(const int32_t k[3], const char* who) {
   for (int i = 0; i < 3; ++i)
     if (k[i] != 1 && k[i] != 3) RX_FAIL(RX_EUNSUPPORTED, "%s: kernel sizes must be 1 or 3", who);
@@ -1075,6 +1132,19 @@ extern "C" int rx_stem_conv_fwd(rx_dtype dt, const float* x_ncdhw, int n, int ci
   if (out->n != n || out->z != z || out->y != y || out->x != x) RX_FAIL(RX_EINVAL, "rx_stem_conv_fwd: geometry mismatch");
   hipStream_t st = (hipStream_t)stream;
   const int TT = kernel[0] * kernel[1] * kernel[2];
+  if (dt != RX_F32 && out->c % 32 == 0 && (out->c * 4) % 16 == 0 && !getenv("RX_NO_STEM32")) {   // one thread per voxel x 32 channels
+    const long V = rx_act_voxels(out);
+    const int G = (int)((V + 255) / 256 > 16384 ? 16384 : (V + 255) / 256);
+    const size_t lds = (size_t)out->c * cin * TT * sizeof(float);
+    if (dt == RX_BF16)
+      hipLaunchKernelGGL((stem_fwd32_kernel<bf16_t>), dim3(G, n), dim3(256), lds, st, x_ncdhw, cin, z, y, x, w, bias, (bf16_t*)out->ptr, out->ld,
+                         V * out->ld, out->c, kernel[0], kernel[1], kernel[2]);
+    else
+      hipLaunchKernelGGL((stem_fwd32_kernel<f16_t>), dim3(G, n), dim3(256), lds, st, x_ncdhw, cin, z, y, x, w, bias, (f16_t*)out->ptr, out->ld,
+                         V * out->ld, out->c, kernel[0], kernel[1], kernel[2]);
+    RX_CHECK_LAUNCH("rx_stem_conv_fwd(32)");
+    return RX_OK;
+  }
   RX_DISPATCH_DTYPE(dt, T, {
     constexpr int P = Elem<T>::PER16;
     long total = rx_act_voxels(out) * (out->c / P);
