@@ -536,6 +536,252 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised, persistent variant of conv_halo_kernel<T,64> on the 4x4x16 tile (the 64/128-channel layers at 64^3
+// and 32^3 and the 64-channel data gradients at 128^3).  The generic kernel runs at 35 % MFMA / 36 % LDS utilisation: per
+// (chunk, dz) phase a workgroup stops twice at a barrier, commits 37-78 KB to LDS and only then issues the next phase's
+// loads.  Here 4 PRODUCER waves stream the next phase's weight plane (and, at a chunk boundary, the next halo) through
+// registers into the other LDS buffer while 4 CONSUMER waves run the phase's 72 MFMAs each from the current one:
+//   LDS = 2 x (9 x 64 weight rows + 648 halo rows) x 64 B = 156,672 B -> one workgroup per CU, one barrier per phase.
+// Rows stay 64 bytes, XOR-swizzled on (row>>2)&3; voxels are dealt to lanes by lane_voxel() (conflict-free lane groups) and
+// the swizzle term of (lane row + tap offset) comes out of a per-lane 32-bit table (one v_bfe per tap and voxel block).
+// A workgroup walks a contiguous range of tiles for one 64-channel output block.
+// ---------------------------------------------------------------------------------------------------------------------
+#define CH64_W_BYTES (9 * 64 * 64)
+#define CH64_X_BYTES (648 * 64)
+
+template <typename T, bool FLIP>
+__global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
+                                                               T* __restrict__ out, const ConvHaloGeom g, int tiles_per_wg) {
+  constexpr int P = Elem<T>::PER16;
+  constexpr int KB = 4 * P;
+  constexpr int TZ = 4, TY = 4, TX = 16, HY = TY + 2, HX = TX + 2, HV = 648;
+  constexpr int XPIECES = (HV * 4 + 255) / 256;   // 11
+  constexpr int WPIECES = 9 * 64 * 4 / 256;       // 9
+  constexpr int CENTRE = HY * HX + HX + 1;        // 127
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sWb = smem;                        // [2][9*64][64 B]
+  unsigned char* sXb = smem + 2 * CH64_W_BYTES;     // [2][648][64 B]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(g.NT, t_begin + tiles_per_wg);
+  const int n0 = blockIdx.y * 64;
+  const int nchunks = g.Ci / KB;
+  const int ppt = 3 * nchunks;                      // phases per tile
+  const int nphase = (t_end - t_begin) * ppt;
+
+  auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0) {
+    const int tx = tile % g.tx_n, t1 = tile / g.tx_n;
+    const int ty = t1 % g.ty_n, t2 = t1 / g.ty_n;
+    const int tz = t2 % g.tz_n;
+    n = t2 / g.tz_n;
+    z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+  };
+
+  if (wave >= 4) {
+    // ================================= producers =================================
+    const int ptid = tid - 256, chunk = ptid & 3;
+    int xh[XPIECES];
+#pragma unroll
+    for (int p = 0; p < XPIECES; ++p) {
+      const int row = (ptid >> 2) + 64 * p;
+      const int hx = row % HX, t = row / HX;
+      xh[p] = row < HV ? ((t / HY) << 16) | ((t % HY) << 8) | hx : -1;
+    }
+    int woff[WPIECES];
+#pragma unroll
+    for (int p = 0; p < WPIECES; ++p) {
+      const int i = ptid + 256 * p;                  // piece ((tl*64 + r)*4 + c4)
+      const int c4 = i & 3, r = (i >> 2) & 63, tl = i >> 8;
+      woff[p] = ((tl * g.Co + n0 + r) * g.Ci) + c4 * P;
+    }
+    const long wplane = (long)9 * g.Co * g.Ci;
+    u32x4 xr[XPIECES], wr[WPIECES];
+    auto load_phase = [&](int ph) {                  // ph relative to this workgroup
+      const int tile = t_begin + ph / ppt, r = ph % ppt, cc = r / 3, dzg = r - cc * 3;
+      const T* wp = w + dzg * wplane + cc * KB;
+#pragma unroll
+      for (int p = 0; p < WPIECES; ++p) wr[p] = *reinterpret_cast<const u32x4*>(wp + woff[p]);
+      if (dzg == 0) {
+        int n, z0, y0, x0;
+        tile_origin(tile, n, z0, y0, x0);
+        const T* in_n = in + (long)n * g.in_ss + cc * KB + chunk * P;
+#pragma unroll
+        for (int p = 0; p < XPIECES; ++p) {
+          u32x4 v = u32x4{0u, 0u, 0u, 0u};
+          if (xh[p] >= 0) {
+            const int z = z0 + (xh[p] >> 16) - 1, y = y0 + ((xh[p] >> 8) & 255) - 1, x = x0 + (xh[p] & 255) - 1;
+            if ((unsigned)z < (unsigned)g.Z && (unsigned)y < (unsigned)g.Y && (unsigned)x < (unsigned)g.X)
+              v = *reinterpret_cast<const u32x4*>(in_n + ((long)(z * g.Y + y) * g.X + x) * g.ldi);
+          }
+          xr[p] = v;
+        }
+      }
+    };
+    auto commit_phase = [&](int ph) {
+      unsigned char* sW = sWb + (ph & 1) * CH64_W_BYTES;
+#pragma unroll
+      for (int p = 0; p < WPIECES; ++p) {
+        const int i = ptid + 256 * p;
+        const int c4 = i & 3, rr = i >> 2;           // rr = tl*64 + r
+        *reinterpret_cast<u32x4*>(sW + rr * 64 + ((c4 ^ ((rr >> 2) & 3)) << 4)) = wr[p];
+      }
+      if (ph % 3 == 0) {                              // (ppt is a multiple of 3: dz == 0 <=> ph % 3 == 0)
+        unsigned char* sX = sXb + ((ph / 3) & 1) * CH64_X_BYTES;
+#pragma unroll
+        for (int p = 0; p < XPIECES; ++p) {
+          const int row = (ptid >> 2) + 64 * p;
+          if (xh[p] >= 0) *reinterpret_cast<u32x4*>(sX + row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4)) = xr[p];
+        }
+      }
+    };
+    if (nphase > 0) {
+      load_phase(0);
+      commit_phase(0);
+      if (nphase > 1) load_phase(1);
+    }
+    lds_only_barrier();
+    for (int ph = 0; ph < nphase; ++ph) {
+      if (ph + 1 < nphase) {
+        commit_phase(ph + 1);                         // buffers of phase ph+1 were last read in phase ph-1 / chunk-2
+        if (ph + 2 < nphase) load_phase(ph + 2);
+      }
+      lds_only_barrier();
+    }
+  } else {
+    // ================================= consumers =================================
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int fv = lane_voxel(fr);
+    unsigned xorg[2], swt[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int v = (wave * 2 + b) * 32 + fv;
+      const int vx = v & 15, vy = (v >> 4) & 3, vz = v >> 6;
+      const int corner = (vz * HY + vy) * HX + vx;      // row of tap (-1,-1,-1) of this voxel
+      xorg[b] = corner * 64;
+      unsigned t = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t |= (unsigned)(fh ^ (((corner + k) >> 2) & 3)) << (2 * k);
+      swt[b] = t;
+    }
+    const int wsw = (fr >> 2) & 3;
+    const unsigned wl0 = fr * 64 + (((0 + fh) ^ wsw) << 4);   // k-step 0; rows tl*64 + a*32 keep (row>>2)&3
+    const unsigned wl1 = fr * 64 + (((2 + fh) ^ wsw) << 4);   // k-step 1
+    const unsigned sW_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)sWb;
+    const unsigned sX_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)sXb;
+
+    f32x16 acc[2][2];
+    auto plane = [&](auto dzc, unsigned wbase, unsigned xbase) {
+      constexpr int DZG = decltype(dzc)::value;
+      constexpr int DEPTH = 3;
+      u32x4 fa[DEPTH + 1][2], fb[DEPTH + 1][2];
+      unsigned xa[2];
+      auto ld = [&](int i, int slot) {
+        const int tl = i >> 1, ks = i & 1;
+        if (ks == 0) {
+          const int dz = FLIP ? 1 - DZG : DZG - 1, dy = FLIP ? 1 - tl / 3 : tl / 3 - 1, dx = FLIP ? 1 - tl % 3 : tl % 3 - 1;
+          const int K = CENTRE + (dz * HY + dy) * HX + dx;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) xa[b] = xbase + xorg[b] + K * 64 + (((swt[b] >> (2 * (K & 15))) & 3u) << 4);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) fa[slot][a] = *(const lds_u32x4*)(uintptr_t)(wbase + (ks ? wl1 : wl0) + (tl * 64 + a * 32) * 64);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) fb[slot][b] = *(const lds_u32x4*)(uintptr_t)(ks ? xa[b] ^ 32u : xa[b]);
+      };
+#pragma unroll
+      for (int i = 0; i < DEPTH; ++i) ld(i, i);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 18; ++i) {
+        if (i + DEPTH < 18) ld(i + DEPTH, (i + DEPTH) % (DEPTH + 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) Mma<T>::run(acc[a][b], fa[i % (DEPTH + 1)][a], fb[i % (DEPTH + 1)][b]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    lds_only_barrier();
+    int ph = 0;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int cc = 0; cc < nchunks; ++cc) {
+        const unsigned xbase = sX_base + ((ph / 3) & 1) * CH64_X_BYTES;
+        plane(std::integral_constant<int, 0>{}, sW_base + (ph & 1) * CH64_W_BYTES, xbase);
+        lds_only_barrier();
+        ++ph;
+        plane(std::integral_constant<int, 1>{}, sW_base + (ph & 1) * CH64_W_BYTES, xbase);
+        lds_only_barrier();
+        ++ph;
+        plane(std::integral_constant<int, 2>{}, sW_base + (ph & 1) * CH64_W_BYTES, xbase);
+        if (cc + 1 < nchunks) {
+          lds_only_barrier();
+          ++ph;
+        }
+      }
+      // ---- epilogue of this tile (its stores stay in flight), then the barrier that ends the tile's last phase
+      int n, z0, y0, x0;
+      tile_origin(tile, n, z0, y0, x0);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int v = (wave * 2 + b) * 32 + fv;
+        const int z = z0 + (v >> 6), y = y0 + ((v >> 4) & 3), x = x0 + (v & 15);
+        if (z >= g.Z || y >= g.Y || x >= g.X) continue;
+        T* op = out + (long)n * g.out_ss + ((long)(z * g.Y + y) * g.X + x) * g.ldo + n0;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int co = a * 32 + 8 * g4 + 4 * fh;
+            T vals[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float f = acc[a][b][4 * g4 + i];
+              if (bias) f += bias[n0 + co + i];
+              if (g.accumulate) f += Elem<T>::to_f(op[co + i]);
+              vals[i] = Elem<T>::from_f(f);
+            }
+            *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
+          }
+      }
+      lds_only_barrier();
+      ++ph;
+    }
+  }
+}
+
+template <typename T>
+static void ch64ws_launch(hipStream_t st, const void* in, const void* w, const float* bias, void* out, const ConvHaloGeom& g) {
+  const size_t lds = (size_t)2 * (CH64_W_BYTES + CH64_X_BYTES);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const int cob = g.Co / 64;
+  int wgs = 256 / cob;                                   // one persistent workgroup per CU in total
+  if (wgs < 1) wgs = 1;
+  if (wgs > g.NT) wgs = g.NT;
+  const int per = (g.NT + wgs - 1) / wgs;
+  wgs = (g.NT + per - 1) / per;
+  dim3 grid(wgs, cob);
+  if (g.flip)
+    hipLaunchKernelGGL((conv_halo64ws_kernel<T, true>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
+  else
+    hipLaunchKernelGGL((conv_halo64ws_kernel<T, false>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
+}
+
 template <typename T>
 static void ch32p_launch(hipStream_t st, const void* in, const void* w, const float* bias, void* out, const ConvHaloGeom& g) {
   const size_t lds = (size_t)CH32P_W_BYTES + 2 * (size_t)CH32P_HALO_BYTES;
@@ -662,6 +908,25 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) {
       rx_set_error("conv_halo32: %s", hipGetErrorString(e2));
+      return RX_ELAUNCH;
+    }
+    return 1;
+  }
+  static int ch64ws = -1;   // RX_CH64WS: 0 off, 1 (default) on for layers with >= 256 (tile, channel block) pairs, 2 always
+  if (ch64ws < 0) {
+    const char* e = getenv("RX_CH64WS");
+    ch64ws = e ? atoi(e) : 1;
+  }
+  if (g.Co % 64 == 0 && TZ == 4 && TY == 4 && TX == 16 && dt != RX_F32 && ch64ws &&
+      (ch64ws == 2 || (long)g.NT * (g.Co / 64) >= 256)) {
+    rx_note_kernel("conv_halo64ws_kernel");
+    if (dt == RX_BF16)
+      ch64ws_launch<bf16_t>(st, in->ptr, w, bias, out->ptr, g);
+    else
+      ch64ws_launch<f16_t>(st, in->ptr, w, bias, out->ptr, g);
+    hipError_t e5 = hipGetLastError();
+    if (e5 != hipSuccess) {
+      rx_set_error("conv_halo64ws: %s", hipGetErrorString(e5));
       return RX_ELAUNCH;
     }
     return 1;

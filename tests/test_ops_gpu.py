@@ -56,6 +56,7 @@ CONV_CASES = [
     (512, 512, (4, 4, 4), (3, 3, 3), (1, 1, 1)),      # bottleneck: 256 panel pairs -> single-split direct wgrad epilogue
     (512, 512, (3, 8, 8), (3, 3, 3), (1, 1, 1)),      # same, several (ragged) tiles per workgroup
     (32, 32, (30, 36, 64), (3, 3, 3), (1, 1, 1)),     # >= 512 tiles of 4x4x16: persistent weight-stationary kernel (ragged z/y)
+    (64, 64, (14, 32, 64), (3, 3, 3), (1, 1, 1)),     # >= 256 tiles, 64 channels: wave-specialised producer/consumer kernel
 ]
 
 
