@@ -151,6 +151,17 @@ int rx_masked_cosine_loss_fwd(const float* pred, const float* target, int n, int
 int rx_masked_cosine_loss_bwd(const float* pred, const float* target, int n, int c, long v, const float* coef,
                               const float* grad_loss, float* dpred, void* stream);
 
+/* ---- optimizer step fused with the weight re-pack (torch.optim.AdamW arithmetic: decoupled weight decay, bias
+ *      correction; train.py:69-86 selects AdamW) -- one pass over a conv / convT weight updates p, exp_avg, exp_avg_sq
+ *      and rewrites both packed copies.  `clip` is an optional DEVICE scalar multiplied into the gradient
+ *      (clip_grad_norm_, train.py:227).  kind 0: Conv3d weight (Co,Ci,T); kind 1: ConvTranspose3d weight (Ci,Co,T).
+ *      rx_adamw_flat: the same update for parameters that have no packed copy (stem, biases, heads). */
+int rx_adamw_pack(rx_dtype dt, float* p, const float* grad, float* exp_avg, float* exp_avg_sq, const float* clip, double lr,
+                  double beta1, double beta2, double eps, double weight_decay, int step, int kind, int A, int B, int taps,
+                  void* w_fwd, void* w_bwd, void* stream);
+int rx_adamw_flat(float* p, const float* grad, float* exp_avg, float* exp_avg_sq, const float* clip, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, int step, long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

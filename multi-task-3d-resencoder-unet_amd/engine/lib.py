@@ -2,7 +2,7 @@
 missing -- there is no fallback path."""
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
 
 import torch
 
@@ -71,6 +71,10 @@ _SIGNATURES = {
     "rx_masked_cosine_loss_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p, c_size_t,
                                           c_void_p]),
     "rx_masked_cosine_loss_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rx_adamw_pack": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_double,
+                              c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rx_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_double, c_int,
+                              c_long, c_void_p]),
 }
 
 _lib = None

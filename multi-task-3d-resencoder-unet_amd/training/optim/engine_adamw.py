@@ -1,0 +1,93 @@
+"""AdamW for the HIP engine: optimizer update, gradient clipping and weight re-pack in one pass.
+
+`torch.optim.AdamW` (what train.py:69-86 builds) followed by the engine's per-step weight re-pack touches every conv
+weight three times per step (clip scale pass, Adam pass, pack pass): 3.7 ms of kernel time at cfg2.  `EngineAdamW` keeps
+torch's `Optimizer` interface (param_groups, state_dict with `step` / `exp_avg` / `exp_avg_sq`, lr schedulers) and
+torch's AdamW arithmetic (decoupled weight decay, bias correction), but its `step()`
+
+  * multiplies the gradient by a DEVICE-scalar clip coefficient on the fly (`clip_grad_norm(max_norm)` below computes the
+    norm exactly like `torch.nn.utils.clip_grad_norm_` and leaves the gradients untouched),
+  * updates a conv / convT weight and rewrites BOTH packed compute-dtype copies of the model's training plan in the same
+    kernel (`rx_adamw_pack`), so the next forward finds fresh packs and re-packs nothing,
+  * updates the un-packed parameters (stem, biases, heads) with `rx_adamw_flat`.
+
+Arithmetic is fp32 like torch's fused kernel; results agree with `torch.optim.AdamW(fused=True)` to fp32 round-off
+(tests/test_optim_gpu.py), not bit for bit (different FMA contraction).  CPU parameters are refused: this optimizer only
+exists for the engine."""
+from ctypes import c_void_p
+
+import torch
+
+from ...engine import lib as _l
+from ...engine.lib import check, load, stream_ptr
+
+
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+class EngineAdamW(torch.optim.Optimizer):
+    def __init__(self, params, model=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.model = model            # NetworkFromConfig whose training plan's packs are rewritten (optional)
+        self._clip = None             # device scalar set by clip_grad_norm(), consumed by the next step()
+
+    # ---- gradient clipping without touching the gradients -------------------------------------------------------
+    @torch.no_grad()
+    def clip_grad_norm(self, max_norm, norm_type=2.0):
+        """same value as torch.nn.utils.clip_grad_norm_ (returned); the scale is applied inside the next step()"""
+        grads = [p.grad for g in self.param_groups for p in g["params"] if p.grad is not None]
+        if not grads:
+            return torch.zeros(())
+        norms = torch._foreach_norm(grads, norm_type)
+        total = torch.linalg.vector_norm(torch.stack(norms), norm_type)
+        self._clip = torch.clamp(max_norm / (total + 1e-6), max=1.0).to(torch.float32).reshape(1)
+        return total
+
+    def _plan(self):
+        plans = [p for p in getattr(self.model, "_plans", {}).values() if p.needs_grad and p.device.type == "cuda"] \
+            if self.model is not None else []
+        return plans[0] if len(plans) == 1 else None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        plan = self._plan()
+        packed = {id(e["param"]): e for e in plan.packs} if plan is not None else {}
+        if plan is not None and plan._side is not None:
+            torch.cuda.current_stream().wait_stream(plan._side)     # nobody may still read the packs / gradients
+        lib = load()
+        clip = self._clip
+        self._clip = None
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise _l.RxError("EngineAdamW updates contiguous fp32 parameters on the HIP device only")
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] = int(st["step"]) + 1
+                ent = packed.get(id(p))
+                if ent is not None:
+                    kind = 0 if ent["kind"] == "conv" else 1
+                    A, B = p.shape[0], p.shape[1]
+                    taps = p[0, 0].numel()
+                    check(lib.rx_adamw_pack(_l.DTYPE_CODE[plan.dtype], _p(p), _p(g), _p(st["exp_avg"]), _p(st["exp_avg_sq"]), _p(clip),
+                                            group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"], kind, A, B, taps,
+                                            _p(ent["w_fwd"]), _p(ent["w_bwd"]), stream_ptr()), "rx_adamw_pack")
+                    ent["version"], ent["ptr"], ent["event"] = p._version, p.data_ptr(), None
+                    ent["epoch"] = getattr(plan.net, "_weights_epoch", 0)
+                else:
+                    check(lib.rx_adamw_flat(_p(p), _p(g), _p(st["exp_avg"]), _p(st["exp_avg_sq"]), _p(clip), group["lr"], b1, b2,
+                                            group["eps"], group["weight_decay"], st["step"], p.numel(), stream_ptr()), "rx_adamw_flat")
+        return loss

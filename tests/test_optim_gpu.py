@@ -1,0 +1,88 @@
+"""GPU (-m gpu): `EngineAdamW` -- AdamW update + gradient clipping + weight re-pack in one pass (csrc rx_adamw_pack /
+rx_adamw_flat) -- against `torch.optim.AdamW(fused=True)` + `clip_grad_norm_` + the engine's own re-pack."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import resenc_oracle as oracle
+from golden_cases import CASES
+from helpers import rel_l2
+
+
+def _setup():
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
+    from mt3d_amd.engine import lib
+    lib.require_device()
+    c = CASES["auto16_2head"]
+    mgr = oracle.make_mgr(c["patch"], c["tasks"], c["in_channels"], c["batch"], c["autoconfigure"], c["model_config"])
+    torch.manual_seed(c["seed"])
+    net = NetworkFromConfig(mgr).cuda()
+    x, targets = oracle.synthetic_batch(c["batch"], c["in_channels"], c["patch"], c["tasks"], 7)
+    return net, c, mgr, x.cuda(), {k: v.cuda() for k, v in targets.items()}, NetworkFromConfig
+
+
+def _train(net, c, x, targets, opt, steps, clip):
+    losses = []
+    for _ in range(steps):
+        net.train()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = net(x)
+        loss = oracle.train_loss(out, targets, c["tasks"])
+        loss.backward()
+        clip(opt)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        losses.append(loss.item())
+    return losses
+
+
+def test_engine_adamw_tracks_torch_adamw():
+    from mt3d_amd.training.optim import EngineAdamW
+    net_a, c, mgr, x, targets, N = _setup()
+    torch.manual_seed(c["seed"])
+    net_b = N(mgr).cuda()
+    pa, pb = [p for p in net_a.parameters()], [p for p in net_b.parameters()]
+    oa = torch.optim.AdamW(pa, lr=1e-3, weight_decay=0.01, fused=True)
+    ob = EngineAdamW(pb, model=net_b, lr=1e-3, weight_decay=0.01)
+    # ONE step from identical weights and (bitwise) identical gradients: the update itself to fp32 round-off, clipping active
+    _train(net_a, c, x, targets, oa, 1, lambda o: torch.nn.utils.clip_grad_norm_(pa, 0.05))
+    _train(net_b, c, x, targets, ob, 1, lambda o: o.clip_grad_norm(0.05))
+    for (n, a), b in zip(net_a.named_parameters(), pb):
+        if a.grad is None and not oa.state.get(a):
+            assert torch.equal(a, b), n
+            continue
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item()), n
+    sa, sb = oa.state[pa[0]], ob.state[pb[0]]
+    assert rel_l2(sb["exp_avg"].cpu(), sa["exp_avg"].cpu()) < 1e-5 and rel_l2(sb["exp_avg_sq"].cpu(), sa["exp_avg_sq"].cpu()) < 1e-5
+    # the packed copies written by the optimizer equal a fresh pack of the updated parameters -> a fresh module agrees
+    fresh = N(mgr).cuda()
+    fresh.load_state_dict(net_b.state_dict())
+
+    def fwd(m):
+        m.train()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return m(x)
+    o1, o2 = fwd(net_b), fwd(fresh)
+    for k in o1:
+        assert torch.equal(o1[k], o2[k]), k
+    plan = [p for p in net_b._plans.values() if p.needs_grad][0]
+    assert all(e.get("event") is None for e in plan.packs)
+
+
+def test_engine_adamw_trains_like_torch_over_several_steps():
+    from mt3d_amd.training.optim import EngineAdamW
+    net_a, c, mgr, x, targets, N = _setup()
+    torch.manual_seed(c["seed"])
+    net_b = N(mgr).cuda()
+    pa, pb = [p for p in net_a.parameters()], [p for p in net_b.parameters()]
+    la = _train(net_a, c, x, targets, torch.optim.AdamW(pa, lr=1e-3, weight_decay=0.0, fused=True), 6,
+                lambda o: torch.nn.utils.clip_grad_norm_(pa, 3))
+    ob = EngineAdamW(pb, model=net_b, lr=1e-3, weight_decay=0.0)
+    lb = _train(net_b, c, x, targets, ob, 6, lambda o: o.clip_grad_norm(3))
+    assert la[-1] < la[0]
+    for a, b in zip(la, lb):          # Adam amplifies round-off on noise-level gradients: trajectories agree loosely
+        assert abs(a - b) < 3e-2 * max(1.0, abs(a)), (la, lb)
+    sd = ob.state_dict()
+    assert set(sd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"}
