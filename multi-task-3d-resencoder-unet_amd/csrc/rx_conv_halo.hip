@@ -550,7 +550,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
 #define CH64_W_BYTES (9 * 64 * 64)
 #define CH64_X_BYTES (648 * 64)
 
-template <typename T, bool FLIP>
+template <typename T, bool FLIP, bool GLDS>
 __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
                                                                T* __restrict__ out, const ConvHaloGeom g, int tiles_per_wg) {
   constexpr int P = Elem<T>::PER16;
@@ -597,12 +597,35 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
       woff[p] = ((tl * g.Co + n0 + r) * g.Ci) + c4 * P;
     }
     const long wplane = (long)9 * g.Co * g.Ci;
+    // GLDS: the weight plane goes global -> LDS directly (global_load_lds_dwordx4: no VGPRs, no ds_write).  One
+    // wave-instruction writes 1 KiB = 16 rows x 64 B lane-linearly, so the XOR swizzle is applied to the SOURCE address:
+    // lane l of piece j holds row (j*4 + pw)*16 + (l>>2), data chunk (l&3) ^ ((row>>2)&3).
+    const int pw = wave - 4, pl = lane;
+    int goff[WPIECES];
+#pragma unroll
+    for (int p = 0; p < WPIECES; ++p) {
+      const int rr = (p * 4 + pw) * 16 + (pl >> 2);        // tl*64 + r
+      const int tl = rr >> 6, r = rr & 63, c4 = (pl & 3) ^ ((rr >> 2) & 3);
+      goff[p] = ((tl * g.Co + n0 + r) * g.Ci) + c4 * P;
+    }
     u32x4 xr[XPIECES], wr[WPIECES];
+    auto dma_weights = [&](int ph) {
+      const int r = ph % ppt, cc = r / 3, dzg = r - cc * 3;
+      const T* wp = w + dzg * wplane + cc * KB;
+      __attribute__((address_space(3))) unsigned char* dst =
+          (__attribute__((address_space(3))) unsigned char*)(sWb + (ph & 1) * CH64_W_BYTES);
+#pragma unroll
+      for (int p = 0; p < WPIECES; ++p)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + goff[p]),
+                                         (__attribute__((address_space(3))) void*)(dst + (p * 4 + pw) * 1024), 16, 0, 0);
+    };
     auto load_phase = [&](int ph) {                  // ph relative to this workgroup
       const int tile = t_begin + ph / ppt, r = ph % ppt, cc = r / 3, dzg = r - cc * 3;
       const T* wp = w + dzg * wplane + cc * KB;
+      if (!GLDS) {
 #pragma unroll
-      for (int p = 0; p < WPIECES; ++p) wr[p] = *reinterpret_cast<const u32x4*>(wp + woff[p]);
+        for (int p = 0; p < WPIECES; ++p) wr[p] = *reinterpret_cast<const u32x4*>(wp + woff[p]);
+      }
       if (dzg == 0) {
         int n, z0, y0, x0;
         tile_origin(tile, n, z0, y0, x0);
@@ -621,11 +644,13 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
     };
     auto commit_phase = [&](int ph) {
       unsigned char* sW = sWb + (ph & 1) * CH64_W_BYTES;
+      if (!GLDS) {
 #pragma unroll
-      for (int p = 0; p < WPIECES; ++p) {
-        const int i = ptid + 256 * p;
-        const int c4 = i & 3, rr = i >> 2;           // rr = tl*64 + r
-        *reinterpret_cast<u32x4*>(sW + rr * 64 + ((c4 ^ ((rr >> 2) & 3)) << 4)) = wr[p];
+        for (int p = 0; p < WPIECES; ++p) {
+          const int i = ptid + 256 * p;
+          const int c4 = i & 3, rr = i >> 2;           // rr = tl*64 + r
+          *reinterpret_cast<u32x4*>(sW + rr * 64 + ((c4 ^ ((rr >> 2) & 3)) << 4)) = wr[p];
+        }
       }
       if (ph % 3 == 0) {                              // (ppt is a multiple of 3: dz == 0 <=> ph % 3 == 0)
         unsigned char* sX = sXb + ((ph / 3) & 1) * CH64_X_BYTES;
@@ -637,15 +662,24 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
       }
     };
     if (nphase > 0) {
+      if (GLDS) dma_weights(0);
       load_phase(0);
       commit_phase(0);
       if (nphase > 1) load_phase(1);
+      if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     lds_only_barrier();
     for (int ph = 0; ph < nphase; ++ph) {
       if (ph + 1 < nphase) {
+        if (GLDS) dma_weights(ph + 1);                // in flight behind the register-staged work of this iteration
         commit_phase(ph + 1);                         // buffers of phase ph+1 were last read in phase ph-1 / chunk-2
         if (ph + 2 < nphase) load_phase(ph + 2);
+        if (GLDS) {                                   // the DMAs must have landed; the halo loads issued after them may fly on
+          if (ph + 2 < nphase && (ph + 2) % 3 == 0)
+            asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
       }
       lds_only_barrier();
     }
@@ -765,8 +799,10 @@ static void ch64ws_launch(hipStream_t st, const void* in, const void* w, const f
   const size_t lds = (size_t)2 * (CH64_W_BYTES + CH64_X_BYTES);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
   const int cob = g.Co / 64;
@@ -776,10 +812,20 @@ static void ch64ws_launch(hipStream_t st, const void* in, const void* w, const f
   const int per = (g.NT + wgs - 1) / wgs;
   wgs = (g.NT + per - 1) / per;
   dim3 grid(wgs, cob);
-  if (g.flip)
-    hipLaunchKernelGGL((conv_halo64ws_kernel<T, true>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
+  static int glds = -1;
+  if (glds < 0) {
+    const char* e = getenv("RX_CH64_GLDS");
+    glds = e ? atoi(e) : 1;   // default: weight planes by LDS-DMA (+2-4 % isolated, -0.1 ms per step, bit-identical)
+  }
+  if (glds) {
+    if (g.flip)
+      hipLaunchKernelGGL((conv_halo64ws_kernel<T, true, true>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
+    else
+      hipLaunchKernelGGL((conv_halo64ws_kernel<T, false, true>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
+  } else if (g.flip)
+    hipLaunchKernelGGL((conv_halo64ws_kernel<T, true, false>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
   else
-    hipLaunchKernelGGL((conv_halo64ws_kernel<T, false>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
+    hipLaunchKernelGGL((conv_halo64ws_kernel<T, false, false>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
 }
 
 template <typename T>
