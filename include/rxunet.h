@@ -105,6 +105,41 @@ int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, const flo
                         float slope, const rx_act* dy, const rx_act* d_residual, int accumulate_residual,
                         void* ws, size_t ws_bytes, void* stream);
 
+/* ---- SqueezeExcite + DropPath of the residual blocks (resblocks.py:79-87,109-112 BasicBlockD; :203-212,234-240
+ *      BottleneckD).  Both classes come from the un-vendored dynamic_network_architectures package: PARITY UNPINNED
+ *      (restated in oracle/resenc_oracle.py).  The block output is
+ *          a = lrelu( mult[n][line][c] * xhat + residual ),   mult = path_scale[n] * gate,
+ *      gate = sigmoid(fc2(relu(fc1(p)))), p = (path_scale[n] * xhat).mean((2, 3)): a 5-D tensor is pooled over (z, y) and
+ *      keeps x (keep_x = 1: line = x), a 4-D tensor (2-D nets, unit z axis here) over (y, x) (keep_x = 0: one line).
+ *      path_scale[n] = bernoulli(keep_prob)/keep_prob of DropPath in training, NULL otherwise. -------------------- */
+typedef struct {
+  const float* w1; /* fc1.weight (rd, C) */
+  const float* b1; /* fc1.bias (rd) */
+  const float* w2; /* fc2.weight (C, rd) */
+  const float* b2; /* fc2.bias (C) */
+  int32_t rd;      /* reduction channels, <= 64 */
+  int32_t keep_x;
+} rx_se_params;
+size_t rx_se_workspace(const rx_act* y);
+/* line sums of y -> pooled [n][L][c] (raw line mean of xhat), hidden [n][L][rd], gate, mult [n][L][c] (all fp32, kept for
+ * the backward).  se == NULL: DropPath only, mult[n][x][c] = path_scale[n] (keep_x = 1 layout), nothing else is written. */
+int rx_se_gate_fwd(rx_dtype dt, const rx_act* y, const float* stats, const float* path_scale, const rx_se_params* se,
+                   float* pooled, float* hidden, float* gate, float* mult, void* ws, size_t ws_bytes, void* stream);
+/* out = lrelu_slope( mult * (y-mean)*rstd + residual ) */
+int rx_instnorm_gate_act_fwd(rx_dtype dt, const rx_act* y, const float* stats, const float* mult, int keep_x,
+                             const rx_act* residual, const rx_act* out, float slope, void* stream);
+/* first backward pass: line sums of g' = g*lrelu'(out) and g'*xhat, gate backward.  Writes dadd [n][L][c] (the pooled
+ * path's contribution to dL/dxhat), m12 [n][c] (the two InstanceNorm backward means) and the fc gradients
+ * (dw1 (rd,C), db1 (rd), dw2 (C,rd), db2 (C); untouched when se == NULL). */
+int rx_se_gate_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out, float slope,
+                   const float* path_scale, const rx_se_params* se, const float* pooled, const float* hidden,
+                   const float* gate, const float* mult, float* dadd, float* m12, float* dw1, float* db1, float* dw2,
+                   float* db2, void* ws, size_t ws_bytes, void* stream);
+/* second pass: dy = rstd*(g'*mult + dadd - m1 - xhat*m2); d_residual (+)= g' */
+int rx_instnorm_gate_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out,
+                             float slope, const float* mult, const float* dadd, const float* m12, int keep_x,
+                             const rx_act* dy, const rx_act* d_residual, int accumulate_residual, void* stream);
+
 /* ---- nn.AvgPool3d(kernel=stride, per axis in {1,2}) (resblocks.py:95) -------------------- */
 int rx_avgpool_fwd(rx_dtype dt, const rx_act* x, const rx_act* y, const int32_t stride[3], void* stream);
 int rx_avgpool_bwd(rx_dtype dt, const rx_act* dy, const rx_act* dx, const int32_t stride[3], int accumulate,

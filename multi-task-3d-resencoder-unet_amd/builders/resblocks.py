@@ -1,8 +1,10 @@
 """Residual block containers (reference: builders/resblocks.py:15-133 BasicBlockD, :135-259
 BottleneckD, :262-353 StackedResidualBlocks).  Unlike the reference this file does not import the
 third-party `dynamic_network_architectures`: the three helpers it took from there have twins in
-this package; SqueezeExcite / DropPath exist only in that package (parity unpinned) and
-are rejected here."""
+this package.  `SqueezeExcite` / `DropPath` exist only in that package (absent from the reference tree and from
+this image): the containers below follow its published source (timm's squeeze_excite.py / drop.py with a
+`conv_op` argument) and the reference's call sites (resblocks.py:79-87, 109-112) -- PARITY UNPINNED, see
+DESIGN.md; their arithmetic runs in csrc/rx_se.hip."""
 import numpy as np
 from torch import nn
 
@@ -10,13 +12,36 @@ from .simple_conv_blocks import ConvDropoutNormReLU, EngineOnly
 from .utils import get_matching_pool_op, maybe_convert_scalar_to_list
 
 
-def _reject_unpinned(stochastic_depth_p, squeeze_excitation):
-    if stochastic_depth_p != 0.0:
-        raise NotImplementedError("stochastic_depth_p > 0 (DropPath) is not available: its arithmetic lives in the "
-                                  "un-vendored dynamic_network_architectures package (parity unpinned)")
-    if squeeze_excitation:
-        raise NotImplementedError("squeeze_excitation=True (SqueezeExcite) is not available: its arithmetic lives in "
-                                  "the un-vendored dynamic_network_architectures package (parity unpinned)")
+def make_divisible(v, divisor=8, min_value=None, round_limit=0.9):
+    """timm's helper behind SqueezeExcite's reduction width (called with round_limit=0.)."""
+    min_value = min_value or divisor
+    new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+    if new_v < round_limit * v:
+        new_v += divisor
+    return new_v
+
+
+class SqueezeExcite(EngineOnly):
+    """Parameter container of the channel gate `x * sigmoid(fc2(relu(fc1(x.mean((2, 3), keepdim=True)))))`
+    (1x1 convs with bias; state_dict keys `fc1.*`, `fc2.*`).  PARITY UNPINNED."""
+
+    def __init__(self, channels, conv_op, rd_ratio=1. / 16, rd_channels=None, rd_divisor=8):
+        super().__init__()
+        if not rd_channels:
+            rd_channels = make_divisible(channels * rd_ratio, rd_divisor, round_limit=0.)
+        self.channels, self.rd_channels = channels, rd_channels
+        self.fc1 = conv_op(channels, rd_channels, kernel_size=1, bias=True)
+        self.fc2 = conv_op(rd_channels, channels, kernel_size=1, bias=True)
+
+
+class DropPath(EngineOnly):
+    """Stochastic depth on the residual branch: in training the branch of sample n is multiplied by
+    bernoulli(1 - drop_prob) / (1 - drop_prob); identity in eval.  No parameters.  PARITY UNPINNED."""
+
+    def __init__(self, drop_prob=0.0, scale_by_keep=True):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+        self.scale_by_keep = scale_by_keep
 
 
 def _make_skip(conv_op, cin, cout, stride, norm_op, norm_op_kwargs):
@@ -34,6 +59,15 @@ def _make_skip(conv_op, cin, cout, stride, norm_op, norm_op_kwargs):
 
 
 class _ResidualBase(EngineOnly):
+    def _regularizers(self, conv_op, cout, stochastic_depth_p, squeeze_excitation, rd_ratio):
+        """same attribute names and creation order as resblocks.py:78-87 (seeded init draws fc1, fc2 before the skip)"""
+        self.apply_stochastic_depth = stochastic_depth_p != 0.0
+        if self.apply_stochastic_depth:
+            self.drop_path = DropPath(drop_prob=stochastic_depth_p)
+        self.apply_se = bool(squeeze_excitation)
+        if self.apply_se:
+            self.squeeze_excitation = SqueezeExcite(cout, conv_op, rd_ratio=rd_ratio, rd_divisor=8)
+
     def _finish(self, conv_op, cin, cout, stride, norm_op, norm_op_kwargs):
         skip = _make_skip(conv_op, cin, cout, stride, norm_op, norm_op_kwargs)
         if skip is None:
@@ -49,7 +83,6 @@ class BasicBlockD(_ResidualBase):
                  norm_op_kwargs=None, dropout_op=None, dropout_op_kwargs=None, nonlin=None, nonlin_kwargs=None,
                  stochastic_depth_p=0.0, squeeze_excitation=False, squeeze_excitation_reduction_ratio=1. / 16):
         super().__init__()
-        _reject_unpinned(stochastic_depth_p, squeeze_excitation)
         self.input_channels, self.output_channels = input_channels, output_channels
         self.stride = maybe_convert_scalar_to_list(conv_op, stride)
         kernel_size = maybe_convert_scalar_to_list(conv_op, kernel_size)
@@ -60,8 +93,8 @@ class BasicBlockD(_ResidualBase):
         self.conv2 = ConvDropoutNormReLU(conv_op, output_channels, output_channels, kernel_size, 1, conv_bias, norm_op,
                                          norm_op_kwargs, None, None, None, None)
         self.nonlin2 = nonlin(**nonlin_kwargs) if nonlin is not None else None
-        self.apply_stochastic_depth = False
-        self.apply_se = False
+        self._regularizers(conv_op, output_channels, stochastic_depth_p, squeeze_excitation,
+                           squeeze_excitation_reduction_ratio)
         self._finish(conv_op, input_channels, output_channels, self.stride, norm_op, norm_op_kwargs)
 
     def main_path(self):
@@ -82,7 +115,6 @@ class BottleneckD(_ResidualBase):
                  nonlin=None, nonlin_kwargs=None, stochastic_depth_p=0.0, squeeze_excitation=False,
                  squeeze_excitation_reduction_ratio=1. / 16):
         super().__init__()
-        _reject_unpinned(stochastic_depth_p, squeeze_excitation)
         self.input_channels, self.output_channels = input_channels, output_channels
         self.bottleneck_channels = bottleneck_channels
         self.stride = maybe_convert_scalar_to_list(conv_op, stride)
@@ -97,8 +129,8 @@ class BottleneckD(_ResidualBase):
         self.conv3 = ConvDropoutNormReLU(conv_op, bottleneck_channels, output_channels, 1, 1, conv_bias, norm_op,
                                          norm_op_kwargs, None, None, None, None)
         self.nonlin3 = nonlin(**nonlin_kwargs) if nonlin is not None else None
-        self.apply_stochastic_depth = False
-        self.apply_se = False
+        self._regularizers(conv_op, output_channels, stochastic_depth_p, squeeze_excitation,
+                           squeeze_excitation_reduction_ratio)
         self._finish(conv_op, input_channels, output_channels, self.stride, norm_op, norm_op_kwargs)
 
     def main_path(self):

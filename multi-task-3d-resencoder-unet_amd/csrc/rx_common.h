@@ -158,3 +158,36 @@ __device__ inline int rx_xcd_remap(int L, int G) {
   const int x = L & 7, slot = L >> 3, chunk = G >> 3, rem = G & 7;
   return x * chunk + (x < rem ? x : rem) + slot;
 }
+
+// Walk order of the 256-voxel output tiles of the halo kernels (a speed choice only: any bijection is correct).
+//   0  raster: x fastest.  A persistent workgroup that walks a contiguous range re-reads the y/z halo rows of every tile
+//      from HBM (PMC: 2.46x the input tensor for the 4x4x16 tile, whose halo is 6x6x18) -- the reuse distance is a whole
+//      x-row (y) or a whole plane (z) of tiles times the 32 workgroups that share the XCD's 4 MiB L2.
+//   1  z fastest, then x, y, n: a persistent workgroup marches along z through a column of tiles, so its z-halo planes
+//      are one tile old (L2 hit), and the workgroups of one XCD (contiguous ranges, rx_xcd_remap) march side by side
+//      through neighbouring columns, so the x/y halos meet in that XCD's L2 at the same time.
+//   2  4x4x4 bricks of tiles (needs tx_n, ty_n, tz_n % 4 == 0): for one-tile-per-workgroup grids, where the 64 workgroups an
+//      XCD runs at a time should cover a compact brick (halo overhead 1.3x instead of 1.6x for a row or column of tiles).
+__device__ __forceinline__ void rx_tile_coords(int t, int tx_n, int ty_n, int tz_n, int order, int& n, int& tz, int& ty, int& tx) {
+  if (order == 1) {
+    tz = t % tz_n;
+    int c = t / tz_n;
+    tx = c % tx_n, c /= tx_n;
+    ty = c % ty_n, n = c / ty_n;
+  } else if (order == 2) {
+    int b = t >> 6;
+    const int i = t & 63, bx_n = tx_n >> 2, by_n = ty_n >> 2, bz_n = tz_n >> 2;
+    const int bx = b % bx_n;
+    b /= bx_n;
+    const int by = b % by_n;
+    b /= by_n;
+    const int bz = b % bz_n;
+    n = b / bz_n;
+    tx = bx * 4 + (i & 3), ty = by * 4 + ((i >> 2) & 3), tz = bz * 4 + (i >> 4);
+  } else {
+    tx = t % tx_n;
+    int c = t / tx_n;
+    ty = c % ty_n, c /= ty_n;
+    tz = c % tz_n, n = c / tz_n;
+  }
+}

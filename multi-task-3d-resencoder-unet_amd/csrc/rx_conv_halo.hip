@@ -23,6 +23,7 @@ struct ConvHaloGeom {
   int TZ, TY, TX, lTX, lTY;
   int HY, HX, HV, VT;
   int tz_n, ty_n, tx_n, NT;
+  int order;                  // tile walk order (rx_tile_coords)
   int accumulate, flip, dbg;  // dbg: ablation mask (RX_DBG env): 1 no halo loads, 2 no weight loads, 4 no MFMA, 8 no stores
 };
 
@@ -53,10 +54,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const T* __restrict__
   u32x4* sW = sX + RX_CH_MAX_HV * 4;                            // [9][BN][4 chunks]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x, n0 = blockIdx.y * BN;
-  int tx = tile % g.tx_n, t1 = tile / g.tx_n;
-  int ty = t1 % g.ty_n, t2 = t1 / g.ty_n;
-  int tz = t2 % g.tz_n, n = t2 / g.tz_n;
+  // logical id: every XCD works through a contiguous range of tiles, the channel blocks of a tile back to back
+  const int lid = g.order ? rx_xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) : blockIdx.x * gridDim.y + blockIdx.y;
+  const int tile = lid / gridDim.y, n0 = (lid - tile * gridDim.y) * BN;
+  int tx, ty, tz, n;
+  rx_tile_coords(tile, g.tx_n, g.ty_n, g.tz_n, g.order, n, tz, ty, tx);
   const int z0 = tz * g.TZ, y0 = ty * g.TY, x0 = tx * g.TX;
   const T* in_n = in + (long)n * g.in_ss;
 
@@ -219,10 +221,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict
   unsigned char* sW = smem + HV * ROWB;        // [9][32][64 B], chunk XOR (row>>2)&3
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x, n0 = blockIdx.y * 32;
-  const int tx = tile % g.tx_n, t1 = tile / g.tx_n;
-  const int ty = t1 % g.ty_n, t2 = t1 / g.ty_n;
-  const int tz = t2 % g.tz_n, n = t2 / g.tz_n;
+  const int lid = g.order ? rx_xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) : blockIdx.x * gridDim.y + blockIdx.y;
+  const int tile = lid / gridDim.y, n0 = (lid - tile * gridDim.y) * 32;
+  int tx, ty, tz, n;
+  rx_tile_coords(tile, g.tx_n, g.ty_n, g.tz_n, g.order, n, tz, ty, tx);
   const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
   const T* in_n = in + (long)n * g.in_ss;
   const int chunk = tid & 3;
@@ -388,7 +390,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(g.NT, t_begin + tiles_per_wg);
+  const int vb = g.order ? rx_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int t_begin = vb * tiles_per_wg, t_end = min(g.NT, t_begin + tiles_per_wg);
 
   // ---- weights: once per workgroup (all 512 threads)
   for (int i = tid; i < 27 * 32 * 4; i += 512) {
@@ -398,10 +401,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
   }
 
   auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0) {
-    const int tx = tile % g.tx_n, t1 = tile / g.tx_n;
-    const int ty = t1 % g.ty_n, t2 = t1 / g.ty_n;
-    const int tz = t2 % g.tz_n;
-    n = t2 / g.tz_n;
+    int tx, ty, tz;
+    rx_tile_coords(tile, g.tx_n, g.ty_n, g.tz_n, g.order, n, tz, ty, tx);
     z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
   };
 
@@ -565,17 +566,17 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(g.NT, t_begin + tiles_per_wg);
-  const int n0 = blockIdx.y * 64;
+  const int lid = g.order ? rx_xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) : blockIdx.x * gridDim.y + blockIdx.y;
+  const int vb = lid / gridDim.y;
+  const int t_begin = vb * tiles_per_wg, t_end = min(g.NT, t_begin + tiles_per_wg);
+  const int n0 = (lid - vb * gridDim.y) * 64;
   const int nchunks = g.Ci / KB;
   const int ppt = 3 * nchunks;                      // phases per tile
   const int nphase = (t_end - t_begin) * ppt;
 
   auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0) {
-    const int tx = tile % g.tx_n, t1 = tile / g.tx_n;
-    const int ty = t1 % g.ty_n, t2 = t1 / g.ty_n;
-    const int tz = t2 % g.tz_n;
-    n = t2 / g.tz_n;
+    int tx, ty, tz;
+    rx_tile_coords(tile, g.tx_n, g.ty_n, g.tz_n, g.order, n, tz, ty, tx);
     z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
   };
 
@@ -919,6 +920,14 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   g.NT = g.N * g.tz_n * g.ty_n * g.tx_n;
   g.accumulate = accumulate, g.flip = flip;
   {
+    static int order = -1;   // RX_TILE_ORDER: 0 raster, 1 (default) locality-aware walk (rx_tile_coords), bit-identical results
+    if (order < 0) {
+      const char* e = getenv("RX_TILE_ORDER");
+      order = e ? atoi(e) : 1;
+    }
+    g.order = order;         // persistent kernels: z-fastest columns; one-tile grids: 4x4x4 bricks where the tile grid allows
+  }
+  {
     static int dbg = -1;
     if (dbg < 0) {
       const char* e = getenv("RX_DBG");
@@ -943,12 +952,14 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
     }
     return 1;
   }
+  ConvHaloGeom g1 = g;                                // one tile per workgroup: bricks of tiles where the tile grid allows
+  if (g.order && g.tx_n % 4 == 0 && g.ty_n % 4 == 0 && g.tz_n % 4 == 0) g1.order = 2;
   if (BN == 32 && TZ == 4 && TY == 4 && TX == 16) {  // full-resolution layers: compile-time tile, padded rows
     rx_note_kernel("conv_halo32_kernel");
     switch (dt) {
-      case RX_F32: ch32_launch<float>(grid, st, in->ptr, w, bias, out->ptr, g); break;
-      case RX_BF16: ch32_launch<bf16_t>(grid, st, in->ptr, w, bias, out->ptr, g); break;
-      case RX_F16: ch32_launch<f16_t>(grid, st, in->ptr, w, bias, out->ptr, g); break;
+      case RX_F32: ch32_launch<float>(grid, st, in->ptr, w, bias, out->ptr, g1); break;
+      case RX_BF16: ch32_launch<bf16_t>(grid, st, in->ptr, w, bias, out->ptr, g1); break;
+      case RX_F16: ch32_launch<f16_t>(grid, st, in->ptr, w, bias, out->ptr, g1); break;
       default: return 0;
     }
     hipError_t e2 = hipGetLastError();
@@ -979,9 +990,9 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   }
   rx_note_kernel(BN == 64 ? "conv_halo_kernel<64>" : "conv_halo_kernel<32>");
   switch (dt) {
-    case RX_F32: ch_dispatch<float>(BN, grid, st, in->ptr, w, bias, out->ptr, g); break;
-    case RX_BF16: ch_dispatch<bf16_t>(BN, grid, st, in->ptr, w, bias, out->ptr, g); break;
-    case RX_F16: ch_dispatch<f16_t>(BN, grid, st, in->ptr, w, bias, out->ptr, g); break;
+    case RX_F32: ch_dispatch<float>(BN, grid, st, in->ptr, w, bias, out->ptr, g1); break;
+    case RX_BF16: ch_dispatch<bf16_t>(BN, grid, st, in->ptr, w, bias, out->ptr, g1); break;
+    case RX_F16: ch_dispatch<f16_t>(BN, grid, st, in->ptr, w, bias, out->ptr, g1); break;
     default: return 0;
   }
   hipError_t e = hipGetLastError();

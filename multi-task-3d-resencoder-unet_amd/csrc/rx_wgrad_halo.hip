@@ -30,6 +30,7 @@ struct WgHaloGeom {
   int S, tiles_per_split, panels_c;
   int sz, sy, sx;        // conv stride per axis (1 or 2); the X halo of a TZ x TY x TX tile of dY is (s*(T-1)+3) per axis
   int Zi, Yi, Xi;        // extent of X (the conv INPUT); Z, Y, X above are the extent of dY
+  int order; // tile walk order (rx_tile_coords)
   int dbg;   // ablation mask (RX_DBG env): 1 stage only the first tile, 2 no MFMA loop
 };
 
@@ -103,9 +104,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const T* __restrict_
   u32x4 gv[RX_WGH_GPIECES], xv[RX_WGH_XPIECES];
   auto load_tile = [&](int tile) {
     // tile -> (n, z0, y0, x0)
-    int tx = tile % g.tx_n, t1 = tile / g.tx_n;
-    int ty = t1 % g.ty_n, t2 = t1 / g.ty_n;
-    int tz = t2 % g.tz_n, n = t2 / g.tz_n;
+    int tx, ty, tz, n;
+    rx_tile_coords(tile, g.tx_n, g.ty_n, g.tz_n, g.order, n, tz, ty, tx);
     const int z0 = tz * g.TZ, y0 = ty * g.TY, x0 = tx * g.TX;
     const T* gn = gt + n * g.g_ss + r0;
     const T* xn = xt + n * g.x_ss + c0;
@@ -325,9 +325,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_halo16_kernel(const T* __restric
   const T* s_gn = gt;
   const T* s_xn = xt;
   auto set_tile = [&](int tile) {       // wave-uniform decode of the tile being staged
-    int tx = tile % g.tx_n, t1 = tile / g.tx_n;
-    int ty = t1 % g.ty_n, t2 = t1 / g.ty_n;
-    int tz = t2 % g.tz_n, n = t2 / g.tz_n;
+    int tx, ty, tz, n;
+    rx_tile_coords(tile, g.tx_n, g.ty_n, g.tz_n, g.order, n, tz, ty, tx);
     s_z0 = tz * 4, s_y0 = ty * 4, s_x0 = tx * 16;
     s_gn = gt + n * g.g_ss + r0 + chunk * 8;
     s_xn = xt + n * g.x_ss + c0 + chunk * 8;
@@ -440,7 +439,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_halo16_kernel(const T* __restric
 // 193 us, together 343 us (32->32 @128^3): in a single instruction stream the two only overlap by the load latency.
 // Here the producers' address arithmetic, load waits and ds_writes run beside the consumers' MFMAs.
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T>
+// DMA = true: the producers move both tiles global -> LDS with buffer_load_dwordx4 ... lds (1 KiB per wave-instruction,
+// lane-linear: exactly the [row][64 B] image this kernel uses), no staging registers, no ds_write pass; voxels outside the
+// volume get an out-of-range buffer offset and the hardware writes ZEROS for them (probed: scripts/probes/buffer_lds_oob.hip).
+template <typename T, bool DMA>
 __global__ __launch_bounds__(512, 1) void wgrad_halo16ws_kernel(const T* __restrict__ gt, const T* __restrict__ xt, float* __restrict__ slab,
                                                                 float* __restrict__ dw, const WgHaloGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x { sG [256][32], sX [648][32] }
@@ -466,9 +468,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo16ws_kernel(const T* __restr
     }
     u32x4 gv[4], xv[WGH16_XPIECES];
     auto load_tile = [&](int tile) {
-      int tx = tile % g.tx_n, t1 = tile / g.tx_n;
-      int ty = t1 % g.ty_n, t2 = t1 / g.ty_n;
-      int tz = t2 % g.tz_n, n = t2 / g.tz_n;
+      int tx, ty, tz, n;
+      rx_tile_coords(tile, g.tx_n, g.ty_n, g.tz_n, g.order, n, tz, ty, tx);
       const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
       const T* gn = gt + n * g.g_ss + r0 + chunk * 8;
       const T* xn = xt + n * g.x_ss + c0 + chunk * 8;
@@ -500,6 +501,48 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo16ws_kernel(const T* __restr
       for (int p = 0; p < WGH16_XPIECES; ++p)
         if (xh[p] >= 0) *reinterpret_cast<u32x4*>(sX + ((ptid >> 2) + 64 * p) * 32 + chunk * 8) = xv[p];
     };
+    if (DMA) {
+      const unsigned OOB = 0x7fffff00u;
+      const long gbytes = (long)g.N * g.g_ss * 2, xbytes = (long)g.N * g.x_ss * 2;
+      __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)gt, 0, (unsigned)(gbytes > 0xfffffff0L ? 0xfffffff0L : gbytes), 0x00020000);
+      __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)xt, 0, (unsigned)(xbytes > 0xfffffff0L ? 0xfffffff0L : xbytes), 0x00020000);
+      const int pw = wave - 4;
+      auto dma_tile = [&](int tile, int buf) {
+        int tx, ty, tz, n;
+        rx_tile_coords(tile, g.tx_n, g.ty_n, g.tz_n, g.order, n, tz, ty, tx);
+        const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
+        const unsigned gbase = (unsigned)((n * g.g_ss + r0 + chunk * 8) * 2);
+        const unsigned xbase = (unsigned)((n * g.x_ss + c0 + chunk * 8) * 2);
+        __attribute__((address_space(3))) unsigned char* lG =
+            (__attribute__((address_space(3))) unsigned char*)(smem + buf * WGH16_BUF_BYTES) + 1024 * pw;
+        __attribute__((address_space(3))) unsigned char* lX = lG + 256 * 64;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int v = (ptid >> 2) + 64 * p;
+          const int z = z0 + (v >> 6), y = y0 + ((v >> 4) & 3), x = x0 + (v & 15);
+          const unsigned off = (z < g.Z && y < g.Y && x < g.X) ? gbase + (unsigned)(((z * g.Y + y) * g.X + x) * g.ldg * 2) : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, (__attribute__((address_space(3))) void*)(lG + 4096 * p), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < WGH16_XPIECES; ++p) {
+          if (xh[p] >= 0) {      // rows >= 648 of the last piece: lanes switched off, nothing is written
+            const int z = z0 + (xh[p] >> 16) - 1, y = y0 + ((xh[p] >> 8) & 255) - 1, x = x0 + (xh[p] & 255) - 1;
+            const bool ok = (unsigned)z < (unsigned)g.Z && (unsigned)y < (unsigned)g.Y && (unsigned)x < (unsigned)g.X;
+            const unsigned off = ok ? xbase + (unsigned)(((z * g.Y + y) * g.X + x) * g.ldx * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)(lX + 4096 * p), 16, off, 0, 0, 0);
+          }
+        }
+      };
+      if (t_begin < t_end) dma_tile(t_begin, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                   // tile 0 visible
+      for (int tile = t_begin; tile < t_end; ++tile) {
+        const int buf = (tile - t_begin) & 1;
+        if (tile + 1 < t_end) dma_tile(tile + 1, buf ^ 1);   // its readers passed the barrier that ended the previous iteration
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    } else {
     if (t_begin < t_end) {
       load_tile(t_begin);
       commit(0);
@@ -513,6 +556,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo16ws_kernel(const T* __restr
         if (tile + 2 < t_end) load_tile(tile + 2);     // in flight during the next iteration's commit-free time
       }
       __syncthreads();
+    }
     }
   } else {
     // ================================= consumers =================================
@@ -667,25 +711,40 @@ int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, const int3
       dbg = e ? atoi(e) : 0;
     }
     g.dbg = dbg;
+    static int order = -1;   // RX_TILE_ORDER: 0 raster, 1 (default) z-fastest walk of each split's tile range (rx_tile_coords)
+    if (order < 0) {
+      const char* e = getenv("RX_TILE_ORDER");
+      order = e ? atoi(e) : 1;
+    }
+    g.order = order;
   }
   if (g.TZ == 4 && g.TY == 4 && g.TX == 16 && g.sz == 1 && g.sy == 1 && g.sx == 1) {   // compile-time tile
     const size_t lds16 = (size_t)WGH16_BUF_BYTES;
     static bool attr16 = false;
-    static int ws_mode = 1;
+    static int ws_mode = 1, dma_mode = 1;
     if (!attr16) {
       const char* e = getenv("RX_WGH_WS");
       ws_mode = e ? atoi(e) : 1;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16ws_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds16));
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16ws_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds16));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16ws_kernel<bf16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds16));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16ws_kernel<f16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds16));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16ws_kernel<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds16));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16ws_kernel<f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds16));
+      const char* ed = getenv("RX_WGH_DMA");
+      dma_mode = ed ? atoi(ed) : 1;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
       attr16 = true;
     }
     rx_note_kernel(ws_mode ? "wgrad_halo16ws_kernel" : "wgrad_halo16_kernel");
-    if (ws_mode && dt == RX_BF16)
-      hipLaunchKernelGGL((wgrad_halo16ws_kernel<bf16_t>), grid, dim3(512), 2 * lds16, st, (const bf16_t*)dy->ptr, (const bf16_t*)x->ptr, (float*)ws, dw, g);
+    const bool dma_ok = dma_mode && (long)g.N * g.g_ss * 2 < 0x7fffff00L && (long)g.N * g.x_ss * 2 < 0x7fffff00L;
+    if (ws_mode && dma_ok && dt == RX_BF16)
+      hipLaunchKernelGGL((wgrad_halo16ws_kernel<bf16_t, true>), grid, dim3(512), 2 * lds16, st, (const bf16_t*)dy->ptr, (const bf16_t*)x->ptr, (float*)ws, dw, g);
+    else if (ws_mode && dma_ok)
+      hipLaunchKernelGGL((wgrad_halo16ws_kernel<f16_t, true>), grid, dim3(512), 2 * lds16, st, (const f16_t*)dy->ptr, (const f16_t*)x->ptr, (float*)ws, dw, g);
+    else if (ws_mode && dt == RX_BF16)
+      hipLaunchKernelGGL((wgrad_halo16ws_kernel<bf16_t, false>), grid, dim3(512), 2 * lds16, st, (const bf16_t*)dy->ptr, (const bf16_t*)x->ptr, (float*)ws, dw, g);
     else if (ws_mode)
-      hipLaunchKernelGGL((wgrad_halo16ws_kernel<f16_t>), grid, dim3(512), 2 * lds16, st, (const f16_t*)dy->ptr, (const f16_t*)x->ptr, (float*)ws, dw, g);
+      hipLaunchKernelGGL((wgrad_halo16ws_kernel<f16_t, false>), grid, dim3(512), 2 * lds16, st, (const f16_t*)dy->ptr, (const f16_t*)x->ptr, (float*)ws, dw, g);
     else if (dt == RX_BF16)
       hipLaunchKernelGGL((wgrad_halo16_kernel<bf16_t>), grid, dim3(256), lds16, st, (const bf16_t*)dy->ptr, (const bf16_t*)x->ptr, (float*)ws, dw, g);
     else

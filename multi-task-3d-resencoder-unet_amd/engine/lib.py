@@ -25,8 +25,15 @@ class RxAct(ctypes.Structure):
                 ("c", c_int32), ("ld", c_int32)]
 
 
+class RxSeParams(ctypes.Structure):
+    """mirror of `rx_se_params` (include/rxunet.h)"""
+    _fields_ = [("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p), ("rd", c_int32),
+                ("keep_x", c_int32)]
+
+
 I3 = c_int32 * 3
 _P = POINTER(RxAct)
+_PSE = POINTER(RxSeParams)
 
 _SIGNATURES = {
     "rx_abi_version": (c_int, []),
@@ -50,6 +57,14 @@ _SIGNATURES = {
     "rx_instnorm_fwd": (c_int, [c_int, _P, c_float, c_void_p, _P, _P, c_float, c_void_p, c_size_t, c_void_p]),
     "rx_instnorm_act_bwd": (c_int, [c_int, _P, _P, c_void_p, _P, c_float, _P, _P, c_int, c_void_p, c_size_t,
                                     c_void_p]),
+    "rx_se_workspace": (c_size_t, [_P]),
+    "rx_se_gate_fwd": (c_int, [c_int, _P, c_void_p, c_void_p, _PSE, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                               c_void_p]),
+    "rx_instnorm_gate_act_fwd": (c_int, [c_int, _P, c_void_p, c_void_p, c_int, _P, _P, c_float, c_void_p]),
+    "rx_se_gate_bwd": (c_int, [c_int, _P, _P, c_void_p, _P, c_float, c_void_p, _PSE, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rx_instnorm_gate_act_bwd": (c_int, [c_int, _P, _P, c_void_p, _P, c_float, c_void_p, c_void_p, c_void_p, c_int, _P, _P,
+                                         c_int, c_void_p]),
     "rx_avgpool_fwd": (c_int, [c_int, _P, _P, I3, c_void_p]),
     "rx_avgpool_bwd": (c_int, [c_int, _P, _P, I3, c_int, c_void_p]),
     "rx_stem_conv_fwd": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, _P, I3,

@@ -249,6 +249,48 @@ def instnorm_act_bwd(g, y, stats, out, dy, slope=0.01, d_residual=None, accumula
                                      int(accumulate_residual), *_ws_args(ws), stream_ptr()), "rx_instnorm_act_bwd")
 
 
+# ---- SqueezeExcite / DropPath fused with InstanceNorm + residual + LeakyReLU ----------------------
+def _se_params(se):
+    """se: dict(w1, b1, w2, b2, rd, keep_x) of fp32 device tensors, or None (DropPath only)"""
+    if se is None:
+        return None
+    return byref(_l.RxSeParams(se["w1"].data_ptr(), se["b1"].data_ptr(), se["w2"].data_ptr(), se["b2"].data_ptr(),
+                               int(se["rd"]), int(se["keep_x"])))
+
+
+def se_workspace_bytes(y):
+    return load().rx_se_workspace(byref(y.desc()))
+
+
+def se_gate_fwd(y, stats, se, pooled, hidden, gate, mult, path_scale=None, ws=None):
+    ws = workspace(se_workspace_bytes(y)) if ws is None else ws
+    check(load().rx_se_gate_fwd(_code(y.dtype), byref(y.desc()), _ptr(stats), _ptr(path_scale), _se_params(se), _ptr(pooled),
+                                _ptr(hidden), _ptr(gate), _ptr(mult), *_ws_args(ws), stream_ptr()), "rx_se_gate_fwd")
+
+
+def instnorm_gate_act_fwd(y, stats, mult, keep_x, out, slope=0.01, residual=None):
+    check(load().rx_instnorm_gate_act_fwd(_code(y.dtype), byref(y.desc()), _ptr(stats), _ptr(mult), int(keep_x),
+                                          byref(residual.desc()) if residual is not None else None, byref(out.desc()),
+                                          float(slope), stream_ptr()), "rx_instnorm_gate_act_fwd")
+
+
+def se_gate_bwd(g, y, stats, out, slope, se, pooled, hidden, gate, mult, dadd, m12, dw1=None, db1=None, dw2=None, db2=None,
+                path_scale=None, ws=None):
+    ws = workspace(se_workspace_bytes(y)) if ws is None else ws
+    check(load().rx_se_gate_bwd(_code(y.dtype), byref(g.desc()), byref(y.desc()), _ptr(stats),
+                                byref(out.desc()) if out is not None else None, float(slope), _ptr(path_scale), _se_params(se),
+                                _ptr(pooled), _ptr(hidden), _ptr(gate), _ptr(mult), _ptr(dadd), _ptr(m12), _ptr(dw1), _ptr(db1),
+                                _ptr(dw2), _ptr(db2), *_ws_args(ws), stream_ptr()), "rx_se_gate_bwd")
+
+
+def instnorm_gate_act_bwd(g, y, stats, out, slope, mult, dadd, m12, keep_x, dy, d_residual=None, accumulate_residual=False):
+    check(load().rx_instnorm_gate_act_bwd(_code(y.dtype), byref(g.desc()), byref(y.desc()), _ptr(stats),
+                                          byref(out.desc()) if out is not None else None, float(slope), _ptr(mult), _ptr(dadd),
+                                          _ptr(m12), int(keep_x), byref(dy.desc()),
+                                          byref(d_residual.desc()) if d_residual is not None else None,
+                                          int(accumulate_residual), stream_ptr()), "rx_instnorm_gate_act_bwd")
+
+
 # ---- pooling ------------------------------------------------------------------------------------
 def avgpool_fwd(x, y, stride):
     check(load().rx_avgpool_fwd(_code(x.dtype), byref(x.desc()), byref(y.desc()), I3(*stride), stream_ptr()),

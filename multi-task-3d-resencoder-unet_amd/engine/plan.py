@@ -184,7 +184,7 @@ class Plan:
 
     # ------------------------------------------------------------------ emitters (forward tape)
     def _emit_cdnr(self, tape, m, x: AT, out: Optional[AT] = None, residual: Optional[AT] = None,
-                   final_slope: Optional[float] = None, first_of_net=False):
+                   final_slope: Optional[float] = None, first_of_net=False, se=None, drop_p=0.0):
         """conv -> (dropout p=0) -> InstanceNorm -> nonlin of one ConvDropoutNormReLU container.
         `residual`/`final_slope` fuse the block epilogue `nonlin(out + residual)` into the same
         elementwise pass.  Returns the activated output."""
@@ -222,8 +222,55 @@ class Plan:
             pk = self._pack(conv.weight, "conv")
             tape.append(Rec("conv", dict(x=x, y=y, pk=pk, b=conv.bias, widx=widx, bidx=bidx, kernel=kernel,
                                          stride=stride)))
-        tape.append(Rec("inact", dict(y=y, stats=stats, eps=eps, res=residual, out=out, slope=slope)))
+        gate = None
+        if se is not None or drop_p > 0.0:
+            gate = self._gate_buffers(odims, cout, se, drop_p)
+        tape.append(Rec("inact", dict(y=y, stats=stats, eps=eps, res=residual, out=out, slope=slope, gate=gate)))
         return out
+
+    def _gate_buffers(self, odims, c, se, drop_p):
+        """SqueezeExcite / DropPath state of one residual block (csrc/rx_se.hip): the fc parameters are read raw (fp32),
+        the small per-(n, line, c) tensors live for the whole step."""
+        keep_x = 0 if (se is not None and self.two_d) else 1      # x.mean((2, 3)) of a 4-D tensor pools every spatial axis
+        L = odims[2] if keep_x else 1
+        f32 = dict(dtype=torch.float32, device=self.device)
+        g = dict(keep_x=keep_x, drop_p=float(drop_p), se=None, scale=None,
+                 mult=torch.empty((self.B, L, c), **f32), dadd=torch.empty((self.B, L, c), **f32),
+                 m12=torch.empty((self.B, c, 2), **f32), pooled=None, hidden=None, gate=None)
+        if drop_p > 0.0:
+            g["scale"] = torch.ones(self.B, **f32)
+        if se is not None:
+            rd = se.fc1.out_channels
+            if rd > 64:
+                raise UnsupportedConfig(f"SqueezeExcite with {rd} reduction channels (the gate kernel holds <= 64)")
+            g["se"] = dict(fc1=se.fc1, fc2=se.fc2, rd=rd, keep_x=keep_x,
+                           idx=[self._param(se.fc1.weight), self._param(se.fc1.bias), self._param(se.fc2.weight),
+                                self._param(se.fc2.bias)])
+            g["pooled"] = torch.empty((self.B, L, c), **f32)
+            g["hidden"] = torch.empty((self.B, L, rd), **f32)
+            g["gate"] = torch.empty((self.B, L, c), **f32)
+        if self.device.type == "cuda":
+            need = 4 * (self.B * 256 * 2 * odims[2] * c + self.B * odims[2] * (3 * c + 64)) + 1024
+            ops.workspace(need, self.device)
+        return g
+
+    @staticmethod
+    def _se_args(g):
+        se = g["se"]
+        if se is None:
+            return None
+        return dict(w1=se["fc1"].weight, b1=se["fc1"].bias, w2=se["fc2"].weight, b2=se["fc2"].bias, rd=se["rd"],
+                    keep_x=se["keep_x"])
+
+    def _draw_path_scale(self, g):
+        """DropPath: per-sample bernoulli(keep)/keep in training, None (identity) in eval"""
+        if g["scale"] is None or not self.net.training:
+            return None
+        keep = 1.0 - g["drop_p"]
+        g["scale"].bernoulli_(keep)
+        if keep > 0.0:
+            g["scale"].div_(keep)
+        return g["scale"]
 
     def _emit_block(self, tape, blk, x: AT, out: Optional[AT] = None):
         """BasicBlockD / BottleneckD: skip path, main path, fused `nonlin(IN(conv_k(..)) + skip)`."""
@@ -241,7 +288,10 @@ class Plan:
         h = x
         for m in path[:-1]:
             h = self._emit_cdnr(tape, m, h)
-        return self._emit_cdnr(tape, path[-1], h, out=out, residual=r, final_slope=_slope_of(blk.final_nonlin()))
+        se = blk.squeeze_excitation if getattr(blk, "apply_se", False) else None
+        drop_p = blk.drop_path.drop_prob if getattr(blk, "apply_stochastic_depth", False) else 0.0
+        return self._emit_cdnr(tape, path[-1], h, out=out, residual=r, final_slope=_slope_of(blk.final_nonlin()),
+                               se=se, drop_p=drop_p)
 
     # ------------------------------------------------------------------ build
     def _build(self):
@@ -374,6 +424,19 @@ class Plan:
                         P._await_pack(a["pk"])
                         ops.convT3d_fwd(a["x"].act, a["pk"]["w_fwd"], a["b"], a["y"].act, a["stride"])
                     f.append(tstep)
+                elif rec.kind == "inact" and a["gate"] is not None:
+                    def gstep(a=a):
+                        g = a["gate"]
+                        res = a["res"].act if a["res"] is not None else None
+                        g["scale_now"] = P._draw_path_scale(g)
+                        if g["se"] is None and g["scale_now"] is None:        # DropPath in eval: the plain block
+                            ops.instnorm_fwd(a["y"].act, a["stats"], a["out"].act, a["slope"], res, a["eps"])
+                            return
+                        ops.instnorm_stats(a["y"].act, a["stats"], a["eps"])
+                        ops.se_gate_fwd(a["y"].act, a["stats"], P._se_args(g), g["pooled"], g["hidden"], g["gate"], g["mult"],
+                                        g["scale_now"])
+                        ops.instnorm_gate_act_fwd(a["y"].act, a["stats"], g["mult"], g["keep_x"], a["out"].act, a["slope"], res)
+                    f.append(gstep)
                 elif rec.kind == "inact":
                     def step(a=a):
                         ops.instnorm_fwd(a["y"].act, a["stats"], a["out"].act, a["slope"],
@@ -488,6 +551,29 @@ class Plan:
                         gres = self._grad_buf(res)
                         acc = view_written(res)
                         res.written = True
+                    def gistep(a=a, gout=gout, dy=dy, gres=gres, acc=acc):
+                        g = a["gate"]
+                        before_dy_write(dy)
+                        if g["se"] is None and g.get("scale_now") is None:
+                            ops.instnorm_act_bwd(gout, a["y"].act, a["stats"],
+                                                 a["out"].act if (a["slope"] != 1.0 and a["res"] is not None) else None, dy,
+                                                 a["slope"], gres, acc)
+                            return
+                        grads = [new_grad(i) for i in g["se"]["idx"]] if g["se"] is not None else [None] * 4
+                        ops.se_gate_bwd(gout, a["y"].act, a["stats"], a["out"].act, a["slope"], P._se_args(g), g["pooled"],
+                                        g["hidden"], g["gate"], g["mult"], g["dadd"], g["m12"], *grads,
+                                        path_scale=g.get("scale_now"))
+                        ops.instnorm_gate_act_bwd(gout, a["y"].act, a["stats"], a["out"].act, a["slope"], g["mult"], g["dadd"],
+                                                  g["m12"], g["keep_x"], dy, gres, acc)
+                        if g["se"] is not None:
+                            for i in g["se"]["idx"]:
+                                done(i)
+                    if a["gate"] is not None:
+                        if a["gate"]["se"] is not None:
+                            order += a["gate"]["se"]["idx"]
+                        b.append(gistep)
+                        continue
+
                     def istep(a=a, gout=gout, dy=dy, gres=gres, acc=acc):
                         before_dy_write(dy)
                         # the saved output is only needed for the mask of residual blocks (sign(out) != sign(xhat) there)

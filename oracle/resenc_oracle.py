@@ -9,10 +9,13 @@ BASELINE train step uses.  Only `tests/`, `__graft_entry__.smoke()` and `bench.p
 Parity status: PINNED.  `tests/test_oracle_vs_reference.py` (runs only where /root/reference
 exists) checks key-for-key `state_dict` equality and forward/backward equality against the real
 reference imported through `oracle/ref_shim.py`; `tests/golden/*.npz` (made by
-`oracle/make_golden.py` from the real reference) pin it everywhere else.  UNPINNED options:
-`squeeze_excitation=True`, `stochastic_depth_p>0` (their arithmetic lives in the un-vendored
-third-party `dynamic_network_architectures`, version unpinned by the reference) -> this oracle
-raises for them.
+`oracle/make_golden.py` from the real reference) pin it everywhere else.  PARITY UNPINNED for two
+options: `squeeze_excitation=True` and `stochastic_depth_p>0`.  Their arithmetic lives in the
+un-vendored third-party `dynamic_network_architectures` (MIC-DKFZ; version unpinned by the reference,
+package absent from this image, no reference test or fixture covers it), so `SqueezeExcite` /
+`DropPath` below restate that package's published source (a copy of timm's squeeze_excite.py /
+drop.py with a `conv_op` argument) anchored on the reference's call sites (resblocks.py:79-87,
+109-112); nothing here could be checked against a run of the real classes.
 
 Each function cites the reference file:line (relative to /root/reference) it follows.
 """
@@ -141,21 +144,76 @@ class StackedConvBlocks(nn.Module):
         return self.convs(x)
 
 
+def make_divisible(v, divisor=8, min_value=None, round_limit=0.9):
+    """timm.layers.helpers.make_divisible, as used by DNA's SqueezeExcite (round_limit=0. there)."""
+    min_value = min_value or divisor
+    new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+    if new_v < round_limit * v:
+        new_v += divisor
+    return new_v
+
+
+class SqueezeExcite(nn.Module):
+    """PARITY UNPINNED.  dynamic_network_architectures.building_blocks.regularization.SqueezeExcite as
+    constructed at builders/resblocks.py:84-87 (`SqueezeExcite(C, conv_op, rd_ratio=1/16, rd_divisor=8)`):
+    fc1 / fc2 are 1x1 convs WITH bias, ReLU between, sigmoid gate, and -- 2-D heritage kept verbatim by
+    the published source -- the squeeze is `x.mean((2, 3), keepdim=True)`: a 5-D activation is pooled over
+    (z, y) only and the gate varies along x."""
+
+    def __init__(self, channels, ops, rd_ratio=1. / 16, rd_divisor=8):
+        super().__init__()
+        rd = make_divisible(channels * rd_ratio, rd_divisor, round_limit=0.)
+        self.fc1 = ops.conv(channels, rd, kernel_size=1, bias=True)
+        self.fc2 = ops.conv(rd, channels, kernel_size=1, bias=True)
+
+    def forward(self, x):
+        x_se = x.mean((2, 3), keepdim=True)
+        x_se = torch.relu(self.fc1(x_se))
+        return x * torch.sigmoid(self.fc2(x_se))
+
+
+class DropPath(nn.Module):
+    """PARITY UNPINNED.  DNA / timm DropPath (builders/resblocks.py:79-81): in training a per-sample
+    bernoulli(keep_prob) mask divided by keep_prob multiplies the residual branch; identity in eval.
+    `forced_scale` (tests only) replaces the random draw by given per-sample factors."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+        self.forced_scale = None
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+        if self.forced_scale is not None:
+            return x * self.forced_scale.to(x.dtype).reshape(shape)
+        r = x.new_empty(shape).bernoulli_(keep)
+        if keep > 0.0:
+            r.div_(keep)
+        return x * r
+
+
 class BasicBlockD(nn.Module):
     """ResNet-D basic block (builders/resblocks.py:15-114).
     out = nonlin( IN(conv2( nonlin(IN(drop(conv1 x))) )) + skip(x) );
     skip = identity | AvgPool(s,s) | 1x1 conv->IN | AvgPool -> 1x1 conv -> IN."""
 
     def __init__(self, ops, cin, cout, kernel, stride, bias, norm_kw, drop_kw, nonlin, nonlin_kw,
-                 stochastic_depth_p=0.0, squeeze_excitation=False):
+                 stochastic_depth_p=0.0, squeeze_excitation=False, rd_ratio=1. / 16):
         super().__init__()
-        if stochastic_depth_p != 0.0 or squeeze_excitation:
-            raise NotImplementedError("DropPath / SqueezeExcite: parity unpinned (third-party DNA)")
         stride = _as_list(stride, ops.dim)
         self.conv1 = ConvDropoutNormReLU(ops, cin, cout, kernel, stride, bias, norm_kw, drop_kw,
                                          nonlin, nonlin_kw)
         self.conv2 = ConvDropoutNormReLU(ops, cout, cout, kernel, 1, bias, norm_kw, None, None, None)
         self.nonlin2 = nonlin(**nonlin_kw)
+        self.apply_stochastic_depth = stochastic_depth_p != 0.0        # resblocks.py:78-81
+        if self.apply_stochastic_depth:
+            self.drop_path = DropPath(stochastic_depth_p)
+        self.apply_se = bool(squeeze_excitation)                       # resblocks.py:83-87
+        if self.apply_se:
+            self.squeeze_excitation = SqueezeExcite(cout, ops, rd_ratio=rd_ratio, rd_divisor=8)
         has_stride = any(s != 1 for s in stride)
         if has_stride or cin != cout:
             seq = []
@@ -170,6 +228,10 @@ class BasicBlockD(nn.Module):
     def forward(self, x):
         res = self.skip(x)
         out = self.conv2(self.conv1(x))
+        if self.apply_stochastic_depth:
+            out = self.drop_path(out)
+        if self.apply_se:
+            out = self.squeeze_excitation(out)
         return self.nonlin2(out + res)
 
 
@@ -177,16 +239,20 @@ class BottleneckD(nn.Module):
     """builders/resblocks.py:135-239: 1x1 -> kxk(stride) -> 1x1, ResNet-D skip."""
 
     def __init__(self, ops, cin, cmid, cout, kernel, stride, bias, norm_kw, drop_kw, nonlin, nonlin_kw,
-                 stochastic_depth_p=0.0, squeeze_excitation=False):
+                 stochastic_depth_p=0.0, squeeze_excitation=False, rd_ratio=1. / 16):
         super().__init__()
-        if stochastic_depth_p != 0.0 or squeeze_excitation:
-            raise NotImplementedError("DropPath / SqueezeExcite: parity unpinned (third-party DNA)")
         stride = _as_list(stride, ops.dim)
         self.conv1 = ConvDropoutNormReLU(ops, cin, cmid, 1, 1, bias, norm_kw, None, nonlin, nonlin_kw)
         self.conv2 = ConvDropoutNormReLU(ops, cmid, cmid, kernel, stride, bias, norm_kw, drop_kw,
                                          nonlin, nonlin_kw)
         self.conv3 = ConvDropoutNormReLU(ops, cmid, cout, 1, 1, bias, norm_kw, None, None, None)
         self.nonlin3 = nonlin(**nonlin_kw)
+        self.apply_stochastic_depth = stochastic_depth_p != 0.0        # resblocks.py:203-206
+        if self.apply_stochastic_depth:
+            self.drop_path = DropPath(stochastic_depth_p)
+        self.apply_se = bool(squeeze_excitation)                       # resblocks.py:208-212
+        if self.apply_se:
+            self.squeeze_excitation = SqueezeExcite(cout, ops, rd_ratio=rd_ratio, rd_divisor=8)
         has_stride = any(s != 1 for s in stride)
         if has_stride or cin != cout:
             seq = []
@@ -201,6 +267,10 @@ class BottleneckD(nn.Module):
     def forward(self, x):
         res = self.skip(x)
         out = self.conv3(self.conv2(self.conv1(x)))
+        if self.apply_stochastic_depth:
+            out = self.drop_path(out)
+        if self.apply_se:
+            out = self.squeeze_excitation(out)
         return self.nonlin3(out + res)
 
 

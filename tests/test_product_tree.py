@@ -69,9 +69,6 @@ def test_no_cpu_fallback_and_loud_rejections():
         net(torch.zeros(2, 1, 16, 16, 16))
     with pytest.raises(RuntimeError):
         net.shared_encoder(torch.zeros(2, 1, 16, 16, 16))       # containers never compute
-    mgr = oracle.make_mgr((16, 16, 16), {"a": {"channels": 1}}, model_config={"squeeze_excitation": True})
-    with pytest.raises(NotImplementedError):
-        NetworkFromConfig(mgr)
     mgr = oracle.make_mgr((16, 16, 16), {"a": {"channels": 1}}, autoconfigure=False, model_config={})
     with pytest.raises(ValueError):
         NetworkFromConfig(mgr)
@@ -88,3 +85,27 @@ def test_yaml_string_blocks_do_not_crash_like_the_reference():
           "n_conv_per_stage_decoder": [1], "strides": [1, 2]}
     net = NetworkFromConfig(oracle.make_mgr((16, 16, 16), {"a": {"channels": 1}}, autoconfigure=False, model_config=mc))
     assert net.shared_encoder.is_residual
+
+
+def test_squeeze_excite_and_droppath_containers_match_the_oracle_tree():
+    """PARITY UNPINNED options (third-party SqueezeExcite / DropPath): same state_dict keys, same seeded init as the
+    oracle's restatement, and the plan wires them (fc parameters registered, gated InstanceNorm steps emitted)."""
+    mc = {"squeeze_excitation": True, "stochastic_depth_p": 0.1}
+    mgr = oracle.make_mgr((16, 16, 16), {"a": {"channels": 1}}, model_config=mc)
+    torch.manual_seed(3)
+    ref = oracle.NetworkFromConfig(mgr)
+    torch.manual_seed(3)
+    net = NetworkFromConfig(mgr)
+    sr, sn = ref.state_dict(), net.state_dict()
+    assert list(sr.keys()) == list(sn.keys())
+    assert any("squeeze_excitation.fc1.weight" in k for k in sn)
+    for k in sr:
+        assert torch.equal(sr[k], sn[k]), k
+    blk = net.shared_encoder.stages[1].blocks[0]
+    assert blk.apply_se and blk.apply_stochastic_depth and blk.squeeze_excitation.rd_channels == 8
+    plan = Plan(net.to("meta"), (2, 1, 16, 16, 16), torch.float32, "meta", True)
+    gated = [r for r in plan.enc_tape if r.kind == "inact" and r.a["gate"] is not None]
+    n_blocks = sum(len(st.blocks) for st in net.shared_encoder.stages)
+    assert len(gated) == n_blocks and all(g.a["gate"]["se"] is not None and g.a["gate"]["keep_x"] == 1 for g in gated)
+    fc = {id(p) for n, p in net.named_parameters() if "squeeze_excitation" in n}
+    assert fc <= {id(p) for p in plan.params}

@@ -29,6 +29,12 @@ VARIANTS = {
     "plain_encoder_relu": dict(patch=(16, 16, 16), cin=2, tasks=ONE, mc=manual(
         basic_encoder_block="ResidualBlock", nonlin="nn.ReLU", n_conv_per_stage_decoder=[2, 1])),
     "two_d": dict(patch=(32, 32), cin=1, tasks=ONE, mc=manual(kernel_sizes=[3, 3, 3])),
+    # PARITY UNPINNED (third-party SqueezeExcite: checked against the oracle's restatement of its published source)
+    "squeeze_excite": dict(patch=(16, 16, 16), cin=1, tasks=ONE, mc=manual(squeeze_excitation=True)),
+    "squeeze_excite_bottleneck": dict(patch=(16, 16, 16), cin=1, tasks=SEG, mc=manual(
+        basic_encoder_block="BottleneckBlockD", bottleneck_block="BottleneckBlockD", bottleneck_channels=[32, 32, 64],
+        squeeze_excitation=True)),
+    "squeeze_excite_2d": dict(patch=(32, 32), cin=1, tasks=ONE, mc=manual(squeeze_excitation=True)),
     "aniso_kernels": dict(patch=(8, 16, 16), cin=1, tasks=ONE, mc=manual(
         kernel_sizes=[[1, 3, 3], [3, 3, 3], [3, 3, 3]], strides=[[1, 1, 1], [1, 2, 2], [2, 2, 2]])),
 }
@@ -103,3 +109,62 @@ def test_unsupported_configs_fail_loudly(NetworkFromConfig):
     net = NetworkFromConfig(mgr).cuda()
     with pytest.raises(UnsupportedConfig):
         net(torch.zeros(1, 8, 16, 16, 16, device="cuda"))
+
+
+def test_droppath_training_and_eval(NetworkFromConfig):
+    """PARITY UNPINNED (third-party DropPath).  Training: the engine's per-sample factors are forced to known values
+    (one sample dropped in the first block, kept and rescaled elsewhere) and handed to the oracle's DropPath; eval: identity."""
+    patch, tasks = (16, 16, 16), ONE
+    mc = manual(squeeze_excitation=True, stochastic_depth_p=0.2)
+    mgr = oracle.make_mgr(patch, tasks, 1, 2, False, mc)
+    torch.manual_seed(5)
+    ref = oracle.NetworkFromConfig(mgr)
+    torch.manual_seed(5)
+    net = NetworkFromConfig(mgr).cuda()
+    net.compute_dtype = torch.float32
+    from mt3d_amd.engine import plan as plan_mod
+    forced = []
+    blocks_r = [m for m in ref.modules() if isinstance(m, oracle.DropPath)]
+
+    def draw(self, g):
+        if g["scale"] is None or not self.net.training:
+            return None
+        i = len(forced)
+        v = torch.tensor([0.0, 1.25] if i == 0 else [1.25, 1.25], dtype=torch.float32)
+        forced.append(v)
+        g["scale"].copy_(v)
+        return g["scale"]
+    orig = plan_mod.Plan._draw_path_scale
+    plan_mod.Plan._draw_path_scale = draw
+    try:
+        x, t = oracle.synthetic_batch(2, 1, patch, tasks, 5)
+        o_n = net(x.cuda())
+        assert len(forced) == len(blocks_r) > 0
+        for m, v in zip(blocks_r, forced):
+            m.forced_scale = v
+        o_r = ref(x)
+        l_r = oracle.train_loss(o_r, t, tasks)
+        l_n = oracle.train_loss(o_n, {k: v.cuda() for k, v in t.items()}, tasks)
+        l_r.backward()
+        l_n.backward()
+    finally:
+        plan_mod.Plan._draw_path_scale = orig
+    for k in o_r:
+        assert rel_l2(o_n[k].cpu(), o_r[k].detach()) < 2e-4
+    pr, pn = dict(ref.named_parameters()), dict(net.named_parameters())
+    for n in pr:
+        assert (pr[n].grad is None) == (pn[n].grad is None), n
+        if pr[n].grad is not None and pr[n].grad.norm() > 1e-6:
+            assert rel_l2(pn[n].grad.cpu(), pr[n].grad) < 3e-2, n
+    # the random draw itself: per-sample values in {0, 1/keep}
+    net(x.cuda())
+    plan = next(iter(net._plans.values()))
+    scales = [r.a["gate"]["scale"] for r in plan.enc_tape if r.kind == "inact" and r.a["gate"] is not None]
+    assert len(scales) == len(blocks_r)
+    for sc in scales:
+        assert all(abs(v) < 1e-6 or abs(v - 1.25) < 1e-6 for v in sc.cpu().tolist())
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        e_r, e_n = ref(x), net(x.cuda())
+    for k in e_r:
+        assert rel_l2(e_n[k].cpu(), e_r[k]) < 2e-4
