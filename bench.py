@@ -44,6 +44,10 @@ WORKLOADS = {
                                "n_conv_per_stage_decoder": [1] * 5, "strides": [1, 2, 2, 2, 2, 2]},
                  tasks={"sheet": {"channels": 1, "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss",
                                   "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}),
+    # cfg2 with the reference's `squeeze_excitation: true` (tasks/dumb.yaml:53, ink.yaml:53): SE gate in all 26 encoder blocks
+    "cfg2se": dict(patch=(128, 128, 128), in_channels=1, batch=2, autoconfigure=True, model_config={"squeeze_excitation": True},
+                   tasks={"sheet": {"channels": 1, "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss",
+                                    "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}),
     # configs[0]: 64^3 plumbing case
     "cfg1": dict(patch=(64, 64, 64), in_channels=1, batch=2, autoconfigure=True, model_config={},
                  tasks={"sheet": {"channels": 1, "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss",

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void se_linesum_kernel(SeView<T> y, SeView<T> 
 #pragma unroll
     for (int j = 0; j < P; ++j) acc[a][j] = 0.f;
   const int r0 = blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+#pragma unroll 4
   for (int r = r0; r < r1; ++r) {
     const long v = (long)r * X + x;
     Vec16<T> yv = ld16(y.ptr + n * y.ss + v * y.ld + cv * P);
@@ -89,29 +90,55 @@ __global__ __launch_bounds__(256) void se_linesum_kernel(SeView<T> y, SeView<T> 
     for (int j = 0; j < P; ++j) p[(size_t)a * X * C + j] = acc[a][j];
 }
 
-// sum the partials of plane `a` for every channel of (n, line) into dst[C] (LDS); all 256 threads take part
-__device__ inline void se_gather_line(const float* __restrict__ part, int n, int chunks, int nacc, int a, int X, int C, int line, int keep_x,
+// sum the partials of all NP planes for every channel of (n, line) into dst[p*C + c] (LDS); all 256 threads take part and
+// every load of a thread is issued before the first barrier (the gate kernels are chains of memory round trips)
+template <int NP>
+__device__ inline void se_gather_line(const float* __restrict__ part, int n, int chunks, int X, int C, int line, int keep_x,
                                       float* __restrict__ dst, float* __restrict__ red) {
   const int tid = threadIdx.x;
-  const int CB = C < 256 ? C : 256, KL = 256 / CB;
   const int XT = keep_x ? 1 : X, nterms = chunks * XT;
-  for (int c0 = 0; c0 < C; c0 += CB) {
-    const int cl = tid % CB, kl = tid / CB, c = c0 + cl;
-    float s = 0.f;
-    if (kl < KL && c < C)
-      for (int t = kl; t < nterms; t += KL) {
+  const size_t plane = (size_t)X * C;
+  if (C >= 256) {          // one thread per channel (and per further 256 channels): no cross-thread step
+    for (int c = tid; c < C; c += 256) {
+      float s[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) s[p] = 0.f;
+#pragma unroll 4
+      for (int t = 0; t < nterms; ++t) {
         const int k = t / XT, x = keep_x ? line : t - k * XT;
-        s += part[((size_t)(n * chunks + k) * nacc + a) * X * C + (size_t)x * C + c];
+        const float* q = part + ((size_t)(n * chunks + k) * NP) * plane + (size_t)x * C + c;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s[p] += q[p * plane];
       }
-    if (kl < KL) red[kl * CB + cl] = s;
-    __syncthreads();
-    if (tid < CB && c0 + tid < C) {
-      float tot = 0.f;
-      for (int q = 0; q < KL; ++q) tot += red[q * CB + tid];
-      dst[c0 + tid] = tot;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) dst[p * C + c] = s[p];
     }
     __syncthreads();
+    return;
   }
+  const int KL = 256 / C, cl = tid % C, kl = tid / C;
+  float s[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) s[p] = 0.f;
+  if (kl < KL) {
+#pragma unroll 4
+    for (int t = kl; t < nterms; t += KL) {
+      const int k = t / XT, x = keep_x ? line : t - k * XT;
+      const float* q = part + ((size_t)(n * chunks + k) * NP) * plane + (size_t)x * C + cl;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) s[p] += q[p * plane];
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) red[(p * KL + kl) * C + cl] = s[p];
+  }
+  __syncthreads();
+  for (int i = tid; i < NP * C; i += 256) {
+    const int p = i / C, c = i - p * C;
+    float tot = 0.f;
+    for (int q = 0; q < KL; ++q) tot += red[(p * KL + q) * C + c];
+    dst[p * C + c] = tot;
+  }
+  __syncthreads();
 }
 
 // ---- gate forward: grid = (lines, N) ----------------------------------------------------------------------------------
@@ -128,7 +155,7 @@ __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restric
   const int line = blockIdx.x, n = blockIdx.y, L = gridDim.x, tid = threadIdx.x;
   const float s = path_scale ? path_scale[n] : 1.f;
   const size_t row = (size_t)n * L + line;
-  se_gather_line(part, n, chunks, 1, 0, X, C, line, keep_x, sp, red);
+  se_gather_line<1>(part, n, chunks, X, C, line, keep_x, sp, red);
   for (int c = tid; c < C; c += 256) {
     const float praw = (sp[c] / R - stats[2 * ((size_t)n * C + c)]) * stats[2 * ((size_t)n * C + c) + 1];
     pooled[row * C + c] = praw;
@@ -164,7 +191,7 @@ __global__ __launch_bounds__(256) void se_fill_mult_kernel(const float* __restri
 }
 
 // ---- gate backward: grid = (lines, N) ---------------------------------------------------------------------------------
-// LDS: sL1[C] | sL2[C] | sds[C] | sdh[64] | red[256]
+// LDS: sL1[C] | sL2[C] | sds[C] | sdh[64] | red[512]
 __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restrict__ part, int chunks, int X, int C, int keep_x, float R,
                                                           const float* __restrict__ path_scale, const float* __restrict__ w1,
                                                           const float* __restrict__ w2, int rd, const float* __restrict__ pooled,
@@ -180,8 +207,7 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restric
   const int line = blockIdx.x, n = blockIdx.y, L = gridDim.x, tid = threadIdx.x;
   const float s = path_scale ? path_scale[n] : 1.f;
   const size_t row = (size_t)n * L + line;
-  se_gather_line(part, n, chunks, 2, 0, X, C, line, keep_x, sL1, red);
-  se_gather_line(part, n, chunks, 2, 1, X, C, line, keep_x, sL2, red);
+  se_gather_line<2>(part, n, chunks, X, C, line, keep_x, sL1, red);     // sL2 = sL1 + C
   if (w1 == nullptr) {   // DropPath only
     for (int c = tid; c < C; c += 256) {
       const float m = mult[row * C + c];
@@ -356,10 +382,11 @@ static SePlan se_plan(const rx_act* y, int per16, int keep_x) {
   p.R = keep_x ? (float)p.rows : (float)p.rows * (float)y->x;
   const int CV = y->c / per16;
   p.segs = (p.X * CV + 255) / 256;
-  long want = 1024 / ((long)y->n * p.segs);
+  // a line-sum thread should stream >= 8 rows, and the gate kernels add `chunks` partials per channel one after the other:
+  // at most 128 chunks (128^3 x 32 channels, batch 2: 512 blocks of 128 rows)
+  long want = p.rows / 8;
   if (want < 1) want = 1;
-  if (want > 256) want = 256;
-  if (want > p.rows) want = p.rows;
+  if (want > 128) want = 128;
   p.rows_per_chunk = (int)((p.rows + want - 1) / want);
   p.chunks = (p.rows + p.rows_per_chunk - 1) / p.rows_per_chunk;
   return p;
@@ -481,7 +508,7 @@ extern "C" int rx_se_gate_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, con
     hipLaunchKernelGGL((se_linesum_kernel<T, true>), dim3(p.chunks, p.segs, y->n), dim3(256), 0, st, se_view<T>(y), se_view<T>(g), ov, stats, p.rows,
                        p.X, y->c, p.rows_per_chunk, slope, part);
   });
-  const size_t lds = (size_t)(3 * C + 64 + 256) * sizeof(float);
+  const size_t lds = (size_t)(3 * C + 64 + 512) * sizeof(float);
   hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(p.L, y->n), dim3(256), lds, st, (const float*)part, p.chunks, p.X, y->c, keep_x, p.R, path_scale,
                      se ? se->w1 : (const float*)nullptr, se ? se->w2 : (const float*)nullptr, se ? se->rd : 0, pooled, hidden, gate, mult, dadd, dz2,
                      dhm, line_m);
