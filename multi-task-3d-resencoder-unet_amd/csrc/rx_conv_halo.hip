@@ -551,7 +551,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
 #define CH64_W_BYTES (9 * 64 * 64)
 #define CH64_X_BYTES (648 * 64)
 
-template <typename T, bool FLIP, bool GLDS>
+template <typename T, bool FLIP, bool GLDS, bool XDMA = false>
 __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
                                                                T* __restrict__ out, const ConvHaloGeom g, int tiles_per_wg) {
   constexpr int P = Elem<T>::PER16;
@@ -620,6 +620,30 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + goff[p]),
                                          (__attribute__((address_space(3))) void*)(dst + (p * 4 + pw) * 1024), 16, 0, 0);
     };
+    // XDMA: the halo goes global -> LDS by buffer_load ... lds as well (same lane-linear 1 KiB pieces, so the row swizzle
+    // is again applied on the source side: (row>>2)&3 == (lane>>4)&3 for every piece); voxels outside the volume get an
+    // out-of-range buffer offset, for which the hardware writes ZEROS (scripts/probes/buffer_lds_oob.hip); the lanes of
+    // rows >= 648 in the last piece are switched off.  No staging registers, no ds_write pass.
+    const int schunk = (pl & 3) ^ ((pl >> 4) & 3);
+    __amdgpu_buffer_rsrc_t rX;
+    if (XDMA) rX = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (unsigned)((long)g.N * g.in_ss * 2), 0x00020000);
+    auto dma_halo = [&](int ph) {
+      const int tile = t_begin + ph / ppt, cc = (ph % ppt) / 3;
+      int n, z0, y0, x0;
+      tile_origin(tile, n, z0, y0, x0);
+      const unsigned base = (unsigned)(((long)n * g.in_ss + cc * KB + schunk * P) * 2);
+      __attribute__((address_space(3))) unsigned char* dst =
+          (__attribute__((address_space(3))) unsigned char*)(sXb + ((ph / 3) & 1) * CH64_X_BYTES);
+#pragma unroll
+      for (int p = 0; p < XPIECES; ++p) {
+        if (xh[p] >= 0) {
+          const int z = z0 + (xh[p] >> 16) - 1, y = y0 + ((xh[p] >> 8) & 255) - 1, x = x0 + (xh[p] & 255) - 1;
+          const bool ok = (unsigned)z < (unsigned)g.Z && (unsigned)y < (unsigned)g.Y && (unsigned)x < (unsigned)g.X;
+          const unsigned off = ok ? base + (unsigned)(((z * g.Y + y) * g.X + x) * g.ldi * 2) : 0x7fffff00u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)(dst + (p * 4 + pw) * 1024), 16, off, 0, 0, 0);
+        }
+      }
+    };
     auto load_phase = [&](int ph) {                  // ph relative to this workgroup
       const int tile = t_begin + ph / ppt, r = ph % ppt, cc = r / 3, dzg = r - cc * 3;
       const T* wp = w + dzg * wplane + cc * KB;
@@ -662,6 +686,32 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
         }
       }
     };
+    if (XDMA) {
+      if (nphase > 0) {
+        dma_weights(0);
+        dma_halo(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      lds_only_barrier();
+      for (int ph = 0; ph < nphase; ++ph) {
+        if (ph + 1 < nphase) {
+          dma_weights(ph + 1);
+          if (ph + 2 < nphase && (ph + 2) % 3 == 0) {
+            // halo of the next chunk into the buffer last read two chunks ago; it only has to land before the barrier
+            // that ends iteration ph+1, so it stays in flight across this one: wave 0 of the producers issues 11 pieces
+            // (the last one partly masked), the others 10 (their 11th is entirely beyond row 648)
+            dma_halo(ph + 2);
+            if (pw == 0)
+              asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            else
+              asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+        }
+        lds_only_barrier();
+      }
+    } else {
     if (nphase > 0) {
       if (GLDS) dma_weights(0);
       load_phase(0);
@@ -683,6 +733,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
         }
       }
       lds_only_barrier();
+    }
     }
   } else {
     // ================================= consumers =================================
@@ -818,7 +869,19 @@ static void ch64ws_launch(hipStream_t st, const void* in, const void* w, const f
     const char* e = getenv("RX_CH64_GLDS");
     glds = e ? atoi(e) : 1;   // default: weight planes by LDS-DMA (+2-4 % isolated, -0.1 ms per step, bit-identical)
   }
-  if (glds) {
+  static int xdma = -1;
+  if (xdma < 0) {
+    const char* e = getenv("RX_CH64_XDMA");
+    xdma = e ? atoi(e) : 1;   // default: the halo by LDS-DMA too
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  if (glds && xdma && (long)g.N * g.in_ss * 2 < 0x7fffff00L) {   // out-of-range offsets must stay out of range of the descriptor
+    if (g.flip)
+      hipLaunchKernelGGL((conv_halo64ws_kernel<T, true, true, true>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
+    else
+      hipLaunchKernelGGL((conv_halo64ws_kernel<T, false, true, true>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
+  } else if (glds) {
     if (g.flip)
       hipLaunchKernelGGL((conv_halo64ws_kernel<T, true, true>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
     else
