@@ -222,6 +222,8 @@ def main():
     # with the next forward (bit-identical parameters).  Off by default: the GPU is throughput-saturated, hiding the
     # HBM-bound update under the forward measured 23.7 vs 23.5 ms per step
     stepper = StreamedOptimizerStep(opt, net) if os.environ.get("RX_STREAMED_STEP", "0") == "1" else None
+    from mt3d_amd.training.optim import clip_and_step
+    fused_clip = os.environ.get("RX_FUSED_CLIP", "1") != "0"   # same update as clip_grad_norm_(3) + step(), one gradient pass less
 
     def step():
         out = net(x)
@@ -232,13 +234,13 @@ def main():
         for name, gt in targets.items():
             loss = loss + loss_fns[name](out[name], gt) * w["tasks"][name].get("weight", 1.0)
         loss.backward()
-        if engine_opt:
-            opt.clip_grad_norm(3)
+        if stepper is not None and not engine_opt:
+            torch.nn.utils.clip_grad_norm_(params, 3)
+            stepper.step()
+        elif fused_clip or engine_opt:
+            clip_and_step(opt, params, 3)       # clip(3) + AdamW; the clip scale rides inside the fused update kernel
         else:
             torch.nn.utils.clip_grad_norm_(params, 3)
-        if stepper is not None and not engine_opt:
-            stepper.step()
-        else:
             opt.step()
         opt.zero_grad(set_to_none=True)
         return loss

@@ -43,7 +43,7 @@ __device__ inline int lane_voxel(int l /* lane & 31 */) {
 
 template <typename T, int BN>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
-                                                           T* __restrict__ out, const ConvHaloGeom g) {
+                                                           T* __restrict__ out, const ConvHaloGeom g, float* __restrict__ slab, int cps) {
   constexpr int P = Elem<T>::PER16;
   constexpr int KB = 4 * P;             // input channels per 64-byte chunk
   constexpr int NB = BN / 32;
@@ -77,12 +77,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const T* __restrict__
       xoff[p] = ok ? (int)(((long)(z * g.Y + y) * g.X + x) * g.ldi) + chunk * P : -1;
     }
   }
+  // split-K (slab != nullptr; the 8^3 layers, whose 32 (tile, channel block) pairs cannot fill 256 CUs): blockIdx.z owns the
+  // 64-byte input-channel chunks [cbeg, cend) and leaves an fp32 partial tile in slab[split][n*V + v][co] (ch_splitk_reduce)
   const int nchunks = g.Ci / KB;
-  const int nphase = nchunks * 3;
+  const int cbeg = slab ? blockIdx.z * cps : 0, cend = slab ? min(nchunks, cbeg + cps) : nchunks;
+  const int nphase = (cend - cbeg) * 3;
 
   u32x4 xr[RX_CH_XPIECES], wr[WPIECES];
   auto prefetch = [&](int ph) {
-    const int cc = ph / 3, dzg = ph - cc * 3;
+    const int cc = cbeg + ph / 3, dzg = ph % 3;
     if (dzg == 0) {
 #pragma unroll
       for (int p = 0; p < RX_CH_XPIECES; ++p) {
@@ -178,6 +181,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const T* __restrict__
     int vx = v & (g.TX - 1), vy = (v >> g.lTX) & (g.TY - 1), vz = v >> (g.lTX + g.lTY);
     int z = z0 + vz, y = y0 + vy, x = x0 + vx;
     if (z >= g.Z || y >= g.Y || x >= g.X) continue;
+    if (slab) {
+      float* sp = slab + (((long)blockIdx.z * g.N + n) * ((long)g.Z * g.Y * g.X) + ((long)(z * g.Y + y) * g.X + x)) * g.Co + n0;
+#pragma unroll
+      for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          *reinterpret_cast<f32x4*>(sp + a * 32 + 8 * g4 + 4 * fh) =
+              f32x4{acc[a][b][4 * g4], acc[a][b][4 * g4 + 1], acc[a][b][4 * g4 + 2], acc[a][b][4 * g4 + 3]};
+      continue;
+    }
     T* op = out + (long)n * g.out_ss + ((long)(z * g.Y + y) * g.X + x) * g.ldo + n0;
 #pragma unroll
     for (int a = 0; a < NB; ++a)
@@ -197,6 +210,33 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const T* __restrict__
         else
           *reinterpret_cast<u32x4*>(op + co) = *reinterpret_cast<u32x4*>(vals);
       }
+  }
+}
+
+// out[row][c] (+)= sum_s slab[s][row][c] (+ bias): fixed order, one thread per 4 channels of a voxel row (row = n*V + v)
+template <typename T>
+__global__ __launch_bounds__(256) void ch_splitk_reduce(const float* __restrict__ slab, int S, long rows, int Co, const float* __restrict__ bias,
+                                                        T* __restrict__ out, int ldo, int accumulate) {
+  const int CV = Co / 4;
+  const long total = rows * CV;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    const long row = i / CV;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < S; ++k) a += *reinterpret_cast<const f32x4*>(slab + ((long)k * rows + row) * Co + cv * 4);
+    T* op = out + row * ldo + cv * 4;
+    T vals[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float f = a[j];
+      if (bias) f += bias[cv * 4 + j];
+      if (accumulate) f += Elem<T>::to_f(op[j]);
+      vals[j] = Elem<T>::from_f(f);
+    }
+    if (sizeof(T) == 2)
+      *reinterpret_cast<u32x2*>(op) = *reinterpret_cast<u32x2*>(vals);
+    else
+      *reinterpret_cast<u32x4*>(op) = *reinterpret_cast<u32x4*>(vals);
   }
 }
 
@@ -930,7 +970,7 @@ static int ch_ilog2(int v) {
 
 template <typename T>
 static void ch_dispatch(int BN, dim3 grid, hipStream_t st, const void* in, const void* w, const float* bias, void* out,
-                        const ConvHaloGeom& g) {
+                        const ConvHaloGeom& g, float* slab = nullptr, int cps = 0) {
   if (BN == 64) {
     const size_t lds = (size_t)(RX_CH_MAX_HV * 4 + 9 * 64 * 4) * 16;
     static bool attr = false;
@@ -938,7 +978,7 @@ static void ch_dispatch(int BN, dim3 grid, hipStream_t st, const void* in, const
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<T, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr = true;
     }
-    hipLaunchKernelGGL((conv_halo_kernel<T, 64>), grid, dim3(256), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g);
+    hipLaunchKernelGGL((conv_halo_kernel<T, 64>), grid, dim3(256), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, slab, cps);
   } else {
     const size_t lds = (size_t)(RX_CH_MAX_HV * 4 + 9 * 32 * 4) * 16;
     static bool attr = false;
@@ -946,14 +986,14 @@ static void ch_dispatch(int BN, dim3 grid, hipStream_t st, const void* in, const
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<T, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr = true;
     }
-    hipLaunchKernelGGL((conv_halo_kernel<T, 32>), grid, dim3(256), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g);
+    hipLaunchKernelGGL((conv_halo_kernel<T, 32>), grid, dim3(256), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, slab, cps);
   }
 }
 
 // returns 1 if handled, 0 to fall through to the generic kernel, negative on error.
 // in/out: same spatial dims (stride 1, kernel 3x3x3, padding 1).  flip = 1 for backward-data.
 int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* bias, const rx_act* out, int flip, int accumulate,
-                     hipStream_t st) {
+                     void* ws, size_t ws_bytes, hipStream_t st) {
   const int per16 = dt == RX_F32 ? 4 : 8;
   const int KB = 4 * per16;
   if (in->c % KB || out->c % 32 || in->ld % per16 || out->ld % 4) return 0;
@@ -1000,7 +1040,63 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   }
   int BN = (g.Co % 64 == 0) ? 64 : 32;
   if (BN == 64 && (long)g.NT * (g.Co / 64) < 256) BN = 32;  // under-filled grid: twice the workgroups, half the work each
-  if ((long)g.NT * (g.Co / BN) < 128) return 0;  // too few workgroups: the split-K gather kernel fills the chip better
+  if ((long)g.NT * (g.Co / BN) < 128) {
+    // too few (tile, channel block) pairs to fill 256 CUs: split the input channels over blockIdx.z, fp32 slabs + a
+    // fixed-order reduce.  Against the split-K gather kernel (igemm_fat) the activations are staged ONCE per chunk with
+    // their halo instead of once per tap -- that kernel moves 340 MB through L2 for a 512->512 layer at 8^3 (216 MB of
+    // it re-gathered activations).  MEASURED (rocprofv3, inside the cfg2 step): 35.7 us + 5.5 us reduce against 36 us +
+    // 5 us for igemm_fat -- no gain: with 3-6 phases per workgroup the kernel is a chain of cold weight-slice fetches
+    // (64-byte pieces of 1 KB rows), not an L2-bandwidth problem.  Kept behind RX_CH_SPLITK=1 (off by default).
+    static int splitk = -1;
+    if (splitk < 0) {
+      const char* e = getenv("RX_CH_SPLITK");
+      splitk = e ? atoi(e) : 0;
+    }
+    const int nchunks = g.Ci / KB;
+    const long base = (long)g.NT * (g.Co / 64);      // the split path always runs the 64-channel-block kernel
+    if (!splitk || !ws || g.Co % 64 || nchunks < 4 || base < 8) return 0;
+    static int target = -1, minch = -1;
+    if (target < 0) {
+      const char* e = getenv("RX_CH_SPLITK_WGS");
+      target = e ? atoi(e) : 256;
+      const char* e2 = getenv("RX_CH_SPLITK_MINCH");
+      minch = e2 ? atoi(e2) : 2;
+    }
+    int S = (int)((target + base - 1) / base);
+    if (S > nchunks / minch) S = nchunks / minch;    // >= 2 chunks (6 phases) per workgroup
+    if (S > 16) S = 16;
+    const int cps = (nchunks + S - 1) / S;
+    S = (nchunks + cps - 1) / cps;
+    const long rows = (long)g.N * g.Z * g.Y * g.X;
+    if (S < 2 || (size_t)S * rows * g.Co * sizeof(float) > ws_bytes) return 0;
+    ConvHaloGeom gs = g;
+    gs.order = 0;
+    dim3 grid3(g.NT, g.Co / 64, S);
+    rx_note_kernel("conv_halo_kernel<64,splitk>");
+    const long total = rows * (g.Co / 4);
+    const int G = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    switch (dt) {
+      case RX_F32:
+        ch_dispatch<float>(64, grid3, st, in->ptr, w, nullptr, out->ptr, gs, (float*)ws, cps);
+        hipLaunchKernelGGL((ch_splitk_reduce<float>), dim3(G), dim3(256), 0, st, (const float*)ws, S, rows, g.Co, bias, (float*)out->ptr, g.ldo, accumulate);
+        break;
+      case RX_BF16:
+        ch_dispatch<bf16_t>(64, grid3, st, in->ptr, w, nullptr, out->ptr, gs, (float*)ws, cps);
+        hipLaunchKernelGGL((ch_splitk_reduce<bf16_t>), dim3(G), dim3(256), 0, st, (const float*)ws, S, rows, g.Co, bias, (bf16_t*)out->ptr, g.ldo, accumulate);
+        break;
+      case RX_F16:
+        ch_dispatch<f16_t>(64, grid3, st, in->ptr, w, nullptr, out->ptr, gs, (float*)ws, cps);
+        hipLaunchKernelGGL((ch_splitk_reduce<f16_t>), dim3(G), dim3(256), 0, st, (const float*)ws, S, rows, g.Co, bias, (f16_t*)out->ptr, g.ldo, accumulate);
+        break;
+      default: return 0;
+    }
+    hipError_t e6 = hipGetLastError();
+    if (e6 != hipSuccess) {
+      rx_set_error("conv_halo split-K: %s", hipGetErrorString(e6));
+      return RX_ELAUNCH;
+    }
+    return 1;
+  }
   dim3 grid(g.NT, g.Co / BN);
   if (BN == 32 && TZ == 4 && TY == 4 && TX == 16 && dt != RX_F32 && g.Ci == 32 && g.Co == 32 && g.NT >= 512 && !getenv("RX_NO_CH32P")) {
     rx_note_kernel("conv_halo32p_kernel");               // 32 -> 32 channels: persistent, weights stationary in LDS

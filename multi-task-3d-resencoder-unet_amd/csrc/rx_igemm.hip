@@ -481,7 +481,7 @@ static int igemm_launch(rx_dtype dt, const void* in, const void* w, const float*
 
 // rx_conv_halo.hip
 int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* bias, const rx_act* out, int flip, int accumulate,
-                     hipStream_t st);
+                     void* ws, size_t ws_bytes, hipStream_t st);
 static bool is_333_s1(const int32_t k[3], const int32_t s[3]) {
   return k[0] == 3 && k[1] == 3 && k[2] == 3 && s[0] == 1 && s[1] == 1 && s[2] == 1;
 }
@@ -513,7 +513,7 @@ extern "C" int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, co
       y->x != conv_out_dim(x->x, kernel[2], stride[2]))
     RX_FAIL(RX_EINVAL, "rx_conv3d_fwd: output geometry mismatch");
   if (is_333_s1(kernel, stride)) {
-    rc = rx_conv_halo_try(dt, x, w_fwd, bias, y, 0, 0, (hipStream_t)stream);  // LDS-halo kernel
+    rc = rx_conv_halo_try(dt, x, w_fwd, bias, y, 0, 0, ws, wsb, (hipStream_t)stream);  // LDS-halo kernel
     if (rc < 0) return rc;
     if (rc == 1) return RX_OK;
   }
@@ -547,7 +547,7 @@ extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_b
       dy->x != conv_out_dim(dx->x, kernel[2], stride[2]))
     RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_data: geometry mismatch");
   if (is_333_s1(kernel, stride)) {
-    rc = rx_conv_halo_try(dt, dy, w_bwd, nullptr, dx, 1, accumulate, (hipStream_t)stream);
+    rc = rx_conv_halo_try(dt, dy, w_bwd, nullptr, dx, 1, accumulate, ws, wsb, (hipStream_t)stream);
     if (rc < 0) return rc;
     if (rc == 1) return RX_OK;
   }

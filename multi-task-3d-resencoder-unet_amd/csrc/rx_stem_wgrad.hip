@@ -50,33 +50,60 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][a][r] = 0.f;
 
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // the next tile's dY pieces and image halo sit in registers while this tile's MFMAs run (the two barriers of a tile
+  // used to enclose the whole global-load latency)
+  constexpr int GP = CO / 8;                       // 16-byte dY pieces per thread
+  constexpr int XP = (HV + 255) / 256;             // halo values per thread and input channel
+  u32x4 gq[GP];
+  float xq[4][XP];
+  auto prefetch = [&](int tile) {
     int tx = tile % tx_n, t1 = tile / tx_n;
     int ty = t1 % ty_n, t2 = t1 / ty_n;
     int tz = t2 % tz_n, n = t2 / tz_n;
     const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
-    __syncthreads();
-    // dY tile: 256 voxels x CO channels, 16-byte pieces
-    for (int i = tid; i < 256 * CO / 8; i += 256) {
+#pragma unroll
+    for (int p = 0; p < GP; ++p) {
+      const int i = tid + 256 * p;
       const int v = i / (CO / 8), cv = i - v * (CO / 8);
       const int z = z0 + (v >> 6), y = y0 + ((v >> 4) & 3), xx = x0 + (v & 15);
       u32x4 val = u32x4{0u, 0u, 0u, 0u};
       if (z < Z && y < Y && xx < X) val = *reinterpret_cast<const u32x4*>(dy + n * sy + ((long)(z * Y + y) * X + xx) * ldy + cv * 8);
-      // panel layout [32-channel panel][voxel][32]
-      const int c = cv * 8;
-      *reinterpret_cast<u32x4*>(sG + ((c >> 5) * 256 + v) * 32 + (c & 31)) = val;
+      gq[p] = val;
     }
-    for (int ci = 0; ci < Cin; ++ci) {
-      const float* xc = x + ((long)n * Cin + ci) * V;
-      for (int i = tid; i < HV; i += 256) {
-        const int hx = i % HX, t = i / HX, hy = t % HY, hz = t / HY;
-        const int z = z0 + hz - 1, y = y0 + hy - 1, xx = x0 + hx - 1;
-        float v = 0.f;
-        if ((unsigned)z < (unsigned)Z && (unsigned)y < (unsigned)Y && (unsigned)xx < (unsigned)X) v = xc[((long)z * Y + y) * X + xx];
-        sX[ci][i] = v;
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      if (ci < Cin) {
+        const float* xc = x + ((long)n * Cin + ci) * V;
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+          const int i = tid + 256 * p;
+          const int hx = i % HX, t = i / HX, hy = t % HY, hz = t / HY;
+          const int z = z0 + hz - 1, y = y0 + hy - 1, xx = x0 + hx - 1;
+          float v = 0.f;
+          if (i < HV && (unsigned)z < (unsigned)Z && (unsigned)y < (unsigned)Y && (unsigned)xx < (unsigned)X) v = xc[((long)z * Y + y) * X + xx];
+          xq[ci][p] = v;
+        }
       }
     }
+  };
+  if (t_begin < t_end) prefetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();
+    // dY tile: 256 voxels x CO channels, panel layout [32-channel panel][voxel][32]
+#pragma unroll
+    for (int p = 0; p < GP; ++p) {
+      const int i = tid + 256 * p;
+      const int v = i / (CO / 8), c = (i - v * (CO / 8)) * 8;
+      *reinterpret_cast<u32x4*>(sG + ((c >> 5) * 256 + v) * 32 + (c & 31)) = gq[p];
+    }
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+      if (ci < Cin)
+#pragma unroll
+        for (int p = 0; p < XP; ++p)
+          if (tid + 256 * p < HV) sX[ci][tid + 256 * p] = xq[ci][p];
+    __syncthreads();
+    if (tile + 1 < t_end) prefetch(tile + 1);
     // this wave's 4 k-steps (16 voxels each = one x-row of the tile)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -134,7 +161,7 @@ int rx_stem_wgrad_mfma_try(rx_dtype dt, const float* x, int n, int cin, int z, i
   if (dt == RX_F32 || (dy->c != 32 && dy->c != 64) || dy->ld % 8 || ((uintptr_t)dy->ptr & 15) || cin > 4) return 0;
   const int NT = n * ((z + 3) / 4) * ((y + 3) / 4) * ((xx + 15) / 16);
   int blocks = NT < max_blocks ? NT : max_blocks;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 768) blocks = 768;       // 3 resident workgroups per CU (44 KB of LDS each): one wave of the chip, no tail
   const int per = (NT + blocks - 1) / blocks;
   blocks = (NT + per - 1) / per;
   const long sy = rx_act_voxels(dy) * (long)dy->ld;

@@ -31,6 +31,7 @@ from .dataloading.dataset import SyntheticPatchDataset, ZarrSegmentationDataset3
 from .engine.ddp import GradSync, broadcast_parameters
 from .engine.streamed_step import StreamedOptimizerStep
 from .training.losses.losses import LOSS_FN_MAP
+from .training.optim import clip_and_step
 
 _AMP = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}
 
@@ -182,11 +183,11 @@ class BaseTrainer:
                 total, per, bsz = forward_loss(batch, True)
                 scaler.scale(total / accum).backward()
                 if (i + 1) % accum == 0 or (i + 1) == len(train_loader):
-                    torch.nn.utils.clip_grad_norm_(params, 3)
                     if stepper is not None and not scaler.is_enabled():
+                        torch.nn.utils.clip_grad_norm_(params, 3)
                         stepper.step()
-                    else:
-                        scaler.step(optimizer)
+                    else:       # clip(3) + step; the clip scale rides inside a fused Adam/AdamW update (training/optim)
+                        clip_and_step(optimizer, params, 3, scaler)
                     scaler.update()
                     optimizer.zero_grad(set_to_none=True)
                 for k, v in per.items():

@@ -86,3 +86,28 @@ def test_engine_adamw_trains_like_torch_over_several_steps():
         assert abs(a - b) < 3e-2 * max(1.0, abs(a)), (la, lb)
     sd = ob.state_dict()
     assert set(sd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_clip_and_step_matches_clip_grad_norm_then_step():
+    """training/optim.clip_and_step: clip(3) + fused AdamW with the clip scale inside the update kernel == the two calls"""
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.training.optim import clip_and_step
+    torch.manual_seed(0)
+    shapes = [(64, 32, 3, 3, 3), (64,), (7, 5), (128, 64, 1, 1, 1)]
+    pa = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = torch.optim.AdamW(pa, lr=1e-2, weight_decay=0.01, fused=True)
+    ob = torch.optim.AdamW(pb, lr=1e-2, weight_decay=0.01, fused=True)
+    for it in range(4):
+        scale = 10.0 if it % 2 == 0 else 0.01           # alternately clipped and not clipped
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a) * scale
+            a.grad, b.grad = g.clone(), g.clone()
+        na = clip_and_step(oa, pa, 3)
+        nb = torch.nn.utils.clip_grad_norm_(pb, 3)
+        ob.step()
+        assert abs(na.item() - nb.item()) <= 1e-5 * nb.item()
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), it
+            assert torch.allclose(a.grad, b.grad, rtol=2e-6, atol=1e-8)      # .grad holds the clipped gradient afterwards
+    assert not hasattr(oa, "grad_scale") and not hasattr(oa, "found_inf")
