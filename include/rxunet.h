@@ -67,6 +67,13 @@ int rx_pack_convT_weight(rx_dtype dt, const float* w, int ci, int co, int taps, 
 size_t rx_conv_workspace_hint(void);
 int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, const float* bias, const rx_act* y,
                   const int32_t kernel[3], const int32_t stride[3], void* ws, size_t ws_bytes, void* stream);
+/* the same plus the InstanceNorm statistics of y (stats[n][c] = (mean, rstd), as rx_instnorm_stats): on the persistent
+ * halo kernels the sums come out of the conv epilogue (per-lane running sums, one wavefront reduction per workgroup) and y
+ * is not read again; otherwise conv followed by rx_instnorm_stats.  ws >= max(rx_conv_workspace_hint(),
+ * rx_instnorm_stats_workspace(y)). */
+int rx_conv3d_fwd_stats(rx_dtype dt, const rx_act* x, const void* w_fwd, const float* bias, const rx_act* y,
+                        const int32_t kernel[3], const int32_t stride[3], float eps, float* stats, void* ws,
+                        size_t ws_bytes, void* stream);
 /* dx (+)= conv_transpose(dy, w): autograd of the above w.r.t. its input */
 int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx,
                        const int32_t kernel[3], const int32_t stride[3], int accumulate, void* ws,

@@ -24,6 +24,8 @@ struct ConvHaloGeom {
   int HY, HX, HV, VT;
   int tz_n, ty_n, tx_n, NT;
   int order;                  // tile walk order (rx_tile_coords)
+  int wgs_s;                  // persistent kernels: workgroups per SAMPLE (tile ranges never straddle samples); 0 = off
+  float* stat_part;           // fused InstanceNorm statistics: per-wave partial sums, or nullptr (see ch_stat_flush)
   int accumulate, flip, dbg;  // dbg: ablation mask (RX_DBG env): 1 no halo loads, 2 no weight loads, 4 no MFMA, 8 no stores
 };
 
@@ -414,6 +416,43 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict
 // write acknowledgements of its epilogue stores (ablation: 1.3 us per tile) although nobody in the kernel reads them
 __device__ inline void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+
+// ---- InstanceNorm statistics in the conv epilogue (persistent kernels, forward) --------------------------------------
+// A consumer lane owns the same 16 (or 2 x 16) output channels for every voxel of every tile its workgroup walks, so the
+// per-(n, c) sums of y and y^2 are RUNNING per-lane sums over the workgroup's whole life (2 VALU per stored value) and the
+// cross-lane step -- a 5-step xor-shuffle over the 32 lanes of a half-wave, which own the same channels -- happens ONCE per
+// workgroup, not per tile (round 1 rejected the per-tile version: ~320 shuffles per wave and tile).  Sums are taken of the
+// values as STORED (rounded to the compute dtype): identical statistics to the separate pass over y.  Each consumer wave
+// writes its own partial row; layout as colreduce_kernel's: part[((n*nchunks + chunk)*2 + a)*Co + c], chunk = wg*4 + wave.
+template <int NA>
+__device__ inline void ch_stat_flush(float (&s1)[NA][16], float (&s2)[NA][16], float* __restrict__ part, int n, int nchunks, int chunk, int Co,
+                                     int n0, int lane) {
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float u = s1[a][r], v = s2[a][r];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        u += __shfl_xor(u, o, 64);
+        v += __shfl_xor(v, o, 64);
+      }
+      s1[a][r] = u, s2[a][r] = v;
+    }
+  if ((lane & 31) == 0) {
+    const int fh = lane >> 5;
+    float* p0 = part + ((size_t)(n * nchunks + chunk) * 2) * Co + n0;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = a * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
+        p0[co] = s1[a][r];
+        p0[Co + co] = s2[a][r];
+      }
+  }
+}
+
 #define CH32P_HALO_BYTES (648 * 80)
 #define CH32P_W_BYTES (27 * 32 * 64)
 
@@ -431,7 +470,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int vb = g.order ? rx_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-  const int t_begin = vb * tiles_per_wg, t_end = min(g.NT, t_begin + tiles_per_wg);
+  int t_begin = vb * tiles_per_wg, t_end = min(g.NT, t_begin + tiles_per_wg);
+  const int NTs = g.NT / g.N;                          // tiles per sample
+  const int sn = g.wgs_s ? vb / g.wgs_s : 0, sl = g.wgs_s ? vb - sn * g.wgs_s : 0;
+  if (g.wgs_s) t_begin = sn * NTs + sl * tiles_per_wg, t_end = min((sn + 1) * NTs, t_begin + tiles_per_wg);
 
   // ---- weights: once per workgroup (all 512 threads)
   for (int i = tid; i < 27 * 32 * 4; i += 512) {
@@ -509,6 +551,9 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
     const unsigned char* wb0 = sW + fr * 64 + (((0 + fh) ^ wsw) << 4);
     const unsigned char* wb1 = sW + fr * 64 + (((2 + fh) ^ wsw) << 4);
     const int sgn = g.flip ? -1 : 1;
+    float s1[1][16], s2[1][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s1[0][r] = 0.f, s2[0][r] = 0.f;
     __syncthreads();                                    // weights + tile 0
     for (int tile = t_begin; tile < t_end; ++tile) {
       const int buf = (tile - t_begin) & 1;
@@ -568,12 +613,18 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
             if (bias) f += bias[co + i];
             if (g.accumulate) f += Elem<T>::to_f(op[co + i]);
             vals[i] = Elem<T>::from_f(f);
+            if (g.stat_part) {
+              const float r = Elem<T>::to_f(vals[i]);
+              s1[0][4 * g4 + i] += r;
+              s2[0][4 * g4 + i] += r * r;
+            }
           }
           *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
         }
       }
       lds_only_barrier();      // the stores of this tile stay in flight under the next tile's MFMAs
     }
+    if (g.stat_part) ch_stat_flush<1>(s1, s2, g.stat_part, sn, g.wgs_s * 4, sl * 4 + wave, g.Co, 0, lane);
   }
 }
 
@@ -591,7 +642,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
 #define CH64_W_BYTES (9 * 64 * 64)
 #define CH64_X_BYTES (648 * 64)
 
-template <typename T, bool FLIP, bool GLDS, bool XDMA = false>
+template <typename T, bool FLIP, bool GLDS, bool XDMA = false, bool STATS = false>
 __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
                                                                T* __restrict__ out, const ConvHaloGeom g, int tiles_per_wg) {
   constexpr int P = Elem<T>::PER16;
@@ -608,7 +659,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lid = g.order ? rx_xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) : blockIdx.x * gridDim.y + blockIdx.y;
   const int vb = lid / gridDim.y;
-  const int t_begin = vb * tiles_per_wg, t_end = min(g.NT, t_begin + tiles_per_wg);
+  int t_begin = vb * tiles_per_wg, t_end = min(g.NT, t_begin + tiles_per_wg);
+  const int NTs = g.NT / g.N;                          // tiles per sample
+  const int sn = g.wgs_s ? vb / g.wgs_s : 0, sl = g.wgs_s ? vb - sn * g.wgs_s : 0;
+  if (g.wgs_s) t_begin = sn * NTs + sl * tiles_per_wg, t_end = min((sn + 1) * NTs, t_begin + tiles_per_wg);
   const int n0 = (lid - vb * gridDim.y) * 64;
   const int nchunks = g.Ci / KB;
   const int ppt = 3 * nchunks;                      // phases per tile
@@ -801,7 +855,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
     f32x16 acc[2][2];
     auto plane = [&](auto dzc, unsigned wbase, unsigned xbase) {
       constexpr int DZG = decltype(dzc)::value;
-      constexpr int DEPTH = 3;
+      constexpr int DEPTH = STATS ? 2 : 3;      // the 64 statistics accumulators leave room for a 3-slot fragment ring only
       u32x4 fa[DEPTH + 1][2], fb[DEPTH + 1][2];
       unsigned xa[2];
       auto ld = [&](int i, int slot) {
@@ -832,6 +886,13 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
       }
     };
 
+    float s1[2][16], s2[2][16];
+    if (STATS) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1[a][r] = 0.f, s2[a][r] = 0.f;
+    }
     lds_only_barrier();
     int ph = 0;
     for (int tile = t_begin; tile < t_end; ++tile) {
@@ -876,6 +937,11 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
               if (bias) f += bias[n0 + co + i];
               if (g.accumulate) f += Elem<T>::to_f(op[co + i]);
               vals[i] = Elem<T>::from_f(f);
+              if (STATS) {
+                const float r = Elem<T>::to_f(vals[i]);
+                s1[a][4 * g4 + i] += r;
+                s2[a][4 * g4 + i] += r * r;
+              }
             }
             *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
           }
@@ -883,6 +949,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
       lds_only_barrier();
       ++ph;
     }
+    if (STATS) ch_stat_flush<2>(s1, s2, g.stat_part, sn, g.wgs_s * 4, sl * 4 + wave, g.Co, n0, lane);
   }
 }
 
@@ -901,8 +968,13 @@ static void ch64ws_launch(hipStream_t st, const void* in, const void* w, const f
   int wgs = 256 / cob;                                   // one persistent workgroup per CU in total
   if (wgs < 1) wgs = 1;
   if (wgs > g.NT) wgs = g.NT;
-  const int per = (g.NT + wgs - 1) / wgs;
-  wgs = (g.NT + per - 1) / per;
+  // a workgroup's tile range never straddles samples (the fused InstanceNorm statistics are per (n, c))
+  const int NTs = g.NT / g.N;
+  int wgs_s = wgs / g.N > 0 ? wgs / g.N : 1;
+  const int per = (NTs + wgs_s - 1) / wgs_s;
+  wgs_s = (NTs + per - 1) / per;
+  wgs = wgs_s * g.N;
+  const_cast<ConvHaloGeom&>(g).wgs_s = wgs_s;
   dim3 grid(wgs, cob);
   static int glds = -1;
   if (glds < 0) {
@@ -916,6 +988,16 @@ static void ch64ws_launch(hipStream_t st, const void* in, const void* w, const f
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
+  if (glds && xdma && g.stat_part && !g.flip && (long)g.N * g.in_ss * 2 < 0x7fffff00L) {
+    static bool attr_s = false;
+    if (!attr_s) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, false, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_s = true;
+    }
+    hipLaunchKernelGGL((conv_halo64ws_kernel<T, false, true, true, true>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
+    return;
+  }
+  const_cast<ConvHaloGeom&>(g).stat_part = nullptr;              // only the instantiation above accumulates statistics
   if (glds && xdma && (long)g.N * g.in_ss * 2 < 0x7fffff00L) {   // out-of-range offsets must stay out of range of the descriptor
     if (g.flip)
       hipLaunchKernelGGL((conv_halo64ws_kernel<T, true, true, true>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
@@ -941,8 +1023,12 @@ static void ch32p_launch(hipStream_t st, const void* in, const void* w, const fl
     attr = true;
   }
   int wgs = g.NT < 256 ? g.NT : 256;                    // one persistent workgroup per CU
-  const int per = (g.NT + wgs - 1) / wgs;
-  wgs = (g.NT + per - 1) / per;
+  const int NTs = g.NT / g.N;                           // a workgroup's tile range never straddles samples
+  int wgs_s = wgs / g.N > 0 ? wgs / g.N : 1;
+  const int per = (NTs + wgs_s - 1) / wgs_s;
+  wgs_s = (NTs + per - 1) / per;
+  wgs = wgs_s * g.N;
+  const_cast<ConvHaloGeom&>(g).wgs_s = wgs_s;
   hipLaunchKernelGGL((conv_halo32p_kernel<T>), dim3(wgs), dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
 }
 
@@ -992,8 +1078,11 @@ static void ch_dispatch(int BN, dim3 grid, hipStream_t st, const void* in, const
 
 // returns 1 if handled, 0 to fall through to the generic kernel, negative on error.
 // in/out: same spatial dims (stride 1, kernel 3x3x3, padding 1).  flip = 1 for backward-data.
+// stat_part / stat_chunks (forward only, optional): when the launch goes to a persistent kernel, per-wave partial sums of
+// y and y^2 are left in stat_part ([n][*stat_chunks][2][Co] floats) and *stat_chunks > 0; otherwise *stat_chunks = 0.
 int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* bias, const rx_act* out, int flip, int accumulate,
-                     void* ws, size_t ws_bytes, hipStream_t st) {
+                     void* ws, size_t ws_bytes, hipStream_t st, float* stat_part, size_t stat_bytes, int* stat_chunks) {
+  if (stat_chunks) *stat_chunks = 0;
   const int per16 = dt == RX_F32 ? 4 : 8;
   const int KB = 4 * per16;
   if (in->c % KB || out->c % 32 || in->ld % per16 || out->ld % 4) return 0;
@@ -1100,6 +1189,8 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   dim3 grid(g.NT, g.Co / BN);
   if (BN == 32 && TZ == 4 && TY == 4 && TX == 16 && dt != RX_F32 && g.Ci == 32 && g.Co == 32 && g.NT >= 512 && !getenv("RX_NO_CH32P")) {
     rx_note_kernel("conv_halo32p_kernel");               // 32 -> 32 channels: persistent, weights stationary in LDS
+    const bool fuse32 = stat_part && stat_chunks && !flip && !accumulate && (size_t)g.N * 1024 * 2 * g.Co * sizeof(float) <= stat_bytes;
+    g.stat_part = fuse32 ? stat_part : nullptr;
     if (dt == RX_BF16)
       ch32p_launch<bf16_t>(st, in->ptr, w, bias, out->ptr, g);
     else
@@ -1109,6 +1200,8 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
       rx_set_error("conv_halo32p: %s", hipGetErrorString(e4));
       return RX_ELAUNCH;
     }
+    if (fuse32) *stat_chunks = g.wgs_s * 4;
+    g.stat_part = nullptr;
     return 1;
   }
   ConvHaloGeom g1 = g;                                // one tile per workgroup: bricks of tiles where the tile grid allows
@@ -1136,6 +1229,13 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   if (g.Co % 64 == 0 && TZ == 4 && TY == 4 && TX == 16 && dt != RX_F32 && ch64ws &&
       (ch64ws == 2 || (long)g.NT * (g.Co / 64) >= 256)) {
     rx_note_kernel("conv_halo64ws_kernel");
+    static int st64 = -1;    // RX_CH64_STATS=0: statistics of the 64-channel-block layers by the separate pass
+    if (st64 < 0) {
+      const char* e = getenv("RX_CH64_STATS");
+      st64 = e ? atoi(e) : 1;
+    }
+    const bool fuse64 = st64 && stat_part && stat_chunks && !flip && !accumulate && (size_t)g.N * 1024 * 2 * g.Co * sizeof(float) <= stat_bytes;
+    g.stat_part = fuse64 ? stat_part : nullptr;
     if (dt == RX_BF16)
       ch64ws_launch<bf16_t>(st, in->ptr, w, bias, out->ptr, g);
     else
@@ -1145,6 +1245,8 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
       rx_set_error("conv_halo64ws: %s", hipGetErrorString(e5));
       return RX_ELAUNCH;
     }
+    if (fuse64 && g.stat_part) *stat_chunks = g.wgs_s * 4;      // (the launcher clears stat_part when it took a variant without them)
+    g.stat_part = nullptr;
     return 1;
   }
   rx_note_kernel(BN == 64 ? "conv_halo_kernel<64>" : "conv_halo_kernel<32>");

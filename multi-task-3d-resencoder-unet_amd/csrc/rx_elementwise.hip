@@ -234,6 +234,12 @@ extern "C" int rx_instnorm_stats(rx_dtype dt, const rx_act* y, float eps, float*
   return RX_OK;
 }
 
+// (mean, rstd) from per-chunk partial sums laid out like colreduce_kernel's (rx_conv_halo.hip leaves such partials behind
+// when a persistent conv kernel accumulates the statistics of its own output)
+void rx_stats_finalize_launch(const float* partial, int N, int nchunks, int C, double V, float eps, float* stats, hipStream_t st) {
+  hipLaunchKernelGGL(colreduce_finalize, dim3((N * C + 3) / 4), dim3(256), 0, st, partial, N, nchunks, 2, C, V, eps, (int)FIN_STATS, stats);
+}
+
 // ---- per-channel sum over (n, voxels) -------------------------------------------------------
 template <typename T>
 struct SumOp {

@@ -481,7 +481,9 @@ static int igemm_launch(rx_dtype dt, const void* in, const void* w, const float*
 
 // rx_conv_halo.hip
 int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* bias, const rx_act* out, int flip, int accumulate,
-                     void* ws, size_t ws_bytes, hipStream_t st);
+                     void* ws, size_t ws_bytes, hipStream_t st, float* stat_part, size_t stat_bytes, int* stat_chunks);
+// rx_elementwise.hip
+void rx_stats_finalize_launch(const float* partial, int N, int nchunks, int C, double V, float eps, float* stats, hipStream_t st);
 static bool is_333_s1(const int32_t k[3], const int32_t s[3]) {
   return k[0] == 3 && k[1] == 3 && k[2] == 3 && s[0] == 1 && s[1] == 1 && s[2] == 1;
 }
@@ -513,7 +515,7 @@ extern "C" int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, co
       y->x != conv_out_dim(x->x, kernel[2], stride[2]))
     RX_FAIL(RX_EINVAL, "rx_conv3d_fwd: output geometry mismatch");
   if (is_333_s1(kernel, stride)) {
-    rc = rx_conv_halo_try(dt, x, w_fwd, bias, y, 0, 0, ws, wsb, (hipStream_t)stream);  // LDS-halo kernel
+    rc = rx_conv_halo_try(dt, x, w_fwd, bias, y, 0, 0, ws, wsb, (hipStream_t)stream, nullptr, 0, nullptr);  // LDS-halo kernel
     if (rc < 0) return rc;
     if (rc == 1) return RX_OK;
   }
@@ -538,6 +540,36 @@ extern "C" int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, co
   return igemm_launch(dt, x->ptr, w_fwd, bias, y->ptr, g, x->n, ws, wsb, (hipStream_t)stream);
 }
 
+// conv + InstanceNorm statistics of its output in one call.  When the layer runs on a persistent halo kernel the sums of y and
+// y^2 come out of the conv epilogue (no extra pass over y); otherwise this is rx_conv3d_fwd followed by rx_instnorm_stats.
+extern "C" int rx_conv3d_fwd_stats(rx_dtype dt, const rx_act* x, const void* w_fwd, const float* bias, const rx_act* y,
+                                   const int32_t kernel[3], const int32_t stride[3], float eps, float* stats, void* ws, size_t wsb,
+                                   void* stream) {
+  if (!rx_act_ok(x) || !rx_act_ok(y) || !w_fwd || !stats || !ws) RX_FAIL(RX_EINVAL, "rx_conv3d_fwd_stats: bad arguments");
+  int rc = check13(kernel, stride, "rx_conv3d_fwd_stats");
+  if (rc) return rc;
+  if (is_333_s1(kernel, stride) && y->n == x->n && y->z == x->z && y->y == x->y && y->x == x->x) {
+    static int fuse = -1;
+    if (fuse < 0) {
+      const char* e = getenv("RX_FUSED_STATS");
+      fuse = e ? atoi(e) : 1;
+    }
+    int chunks = 0;
+    rc = rx_conv_halo_try(dt, x, w_fwd, bias, y, 0, 0, nullptr, 0, (hipStream_t)stream, fuse ? (float*)ws : nullptr, wsb, &chunks);
+    if (rc < 0) return rc;
+    if (rc == 1 && chunks > 0) {
+      rx_stats_finalize_launch((const float*)ws, y->n, chunks, y->c, (double)rx_act_voxels(y), eps, stats, (hipStream_t)stream);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) RX_FAIL(RX_ELAUNCH, "rx_conv3d_fwd_stats(finalize): %s", hipGetErrorString(e));
+      return RX_OK;
+    }
+    if (rc == 1) return rx_instnorm_stats(dt, y, eps, stats, ws, wsb, stream);
+  }
+  rc = rx_conv3d_fwd(dt, x, w_fwd, bias, y, kernel, stride, ws, wsb, stream);
+  if (rc) return rc;
+  return rx_instnorm_stats(dt, y, eps, stats, ws, wsb, stream);
+}
+
 extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx, const int32_t kernel[3],
                                   const int32_t stride[3], int accumulate, void* ws, size_t wsb, void* stream) {
   if (!rx_act_ok(dy) || !rx_act_ok(dx) || !w_bwd) RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_data: bad arguments");
@@ -547,7 +579,7 @@ extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_b
       dy->x != conv_out_dim(dx->x, kernel[2], stride[2]))
     RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_data: geometry mismatch");
   if (is_333_s1(kernel, stride)) {
-    rc = rx_conv_halo_try(dt, dy, w_bwd, nullptr, dx, 1, accumulate, ws, wsb, (hipStream_t)stream);
+    rc = rx_conv_halo_try(dt, dy, w_bwd, nullptr, dx, 1, accumulate, ws, wsb, (hipStream_t)stream, nullptr, 0, nullptr);
     if (rc < 0) return rc;
     if (rc == 1) return RX_OK;
   }

@@ -174,6 +174,20 @@ def conv3d_fwd(x, w_fwd, bias, y, kernel, stride, ws=None):
     _PROF.run("fwd:" + LaunchProfiler.igemm_name(y.voxels, y.c), 2.0 * n * y.voxels * y.c * x.c * _taps(kernel), 1, go)
 
 
+def conv3d_fwd_stats(x, w_fwd, bias, y, kernel, stride, stats, eps=1e-5, ws=None):
+    """conv + InstanceNorm statistics of its output (fused into the conv epilogue on the persistent halo kernels)"""
+    ws = workspace() if ws is None else ws
+
+    def go():
+        check(load().rx_conv3d_fwd_stats(_code(x.dtype), byref(x.desc()), _ptr(w_fwd), _ptr(bias), byref(y.desc()),
+                                         I3(*kernel), I3(*stride), float(eps), _ptr(stats), *_ws_args(ws), stream_ptr()),
+              "rx_conv3d_fwd_stats")
+    if _PROF is None:
+        return go()
+    n = y.dims[0]
+    _PROF.run("fwd:" + LaunchProfiler.igemm_name(y.voxels, y.c), 2.0 * n * y.voxels * y.c * x.c * _taps(kernel), 1, go)
+
+
 def conv3d_bwd_data(dy, w_bwd, dx, kernel, stride, accumulate=False, ws=None):
     ws = workspace() if ws is None else ws
 

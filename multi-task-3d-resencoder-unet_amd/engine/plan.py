@@ -410,6 +410,15 @@ class Plan:
         P = self
         f = self.fwd
         for tape in [self.enc_tape] + self.dec_tapes:
+            # conv -> InstanceNorm pairs whose statistics can come out of the conv epilogue (rx_conv3d_fwd_stats): 3x3x3
+            # stride-1 layers in a 16-bit compute type, above the size the single-launch InstanceNorm kernel takes
+            for i, rec in enumerate(tape[:-1]):
+                nxt = tape[i + 1]
+                if (rec.kind == "conv" and nxt.kind == "inact" and nxt.a["y"] is rec.a["y"] and self.dtype != torch.float32
+                        and list(rec.a["kernel"]) == [3, 3, 3] and list(rec.a["stride"]) == [1, 1, 1]
+                        and rec.a["y"].act.voxels > 512 and rec.a["y"].act.dims[3] >= 16):
+                    rec.a["stats_to"] = nxt.a
+                    nxt.a["stats_done"] = True
             for rec in tape:
                 a = rec.a
                 if rec.kind == "stem":
@@ -417,7 +426,12 @@ class Plan:
                 elif rec.kind == "conv":
                     def cstep(a=a):
                         P._await_pack(a["pk"])
-                        ops.conv3d_fwd(a["x"].act, a["pk"]["w_fwd"], a["b"], a["y"].act, a["kernel"], a["stride"])
+                        st = a.get("stats_to")
+                        if st is not None:
+                            ops.conv3d_fwd_stats(a["x"].act, a["pk"]["w_fwd"], a["b"], a["y"].act, a["kernel"], a["stride"],
+                                                 st["stats"], st["eps"])
+                        else:
+                            ops.conv3d_fwd(a["x"].act, a["pk"]["w_fwd"], a["b"], a["y"].act, a["kernel"], a["stride"])
                     f.append(cstep)
                 elif rec.kind == "convT":
                     def tstep(a=a):
@@ -432,15 +446,19 @@ class Plan:
                         if g["se"] is None and g["scale_now"] is None:        # DropPath in eval: the plain block
                             ops.instnorm_fwd(a["y"].act, a["stats"], a["out"].act, a["slope"], res, a["eps"])
                             return
-                        ops.instnorm_stats(a["y"].act, a["stats"], a["eps"])
+                        if not a.get("stats_done"):
+                            ops.instnorm_stats(a["y"].act, a["stats"], a["eps"])
                         ops.se_gate_fwd(a["y"].act, a["stats"], P._se_args(g), g["pooled"], g["hidden"], g["gate"], g["mult"],
                                         g["scale_now"])
                         ops.instnorm_gate_act_fwd(a["y"].act, a["stats"], g["mult"], g["keep_x"], a["out"].act, a["slope"], res)
                     f.append(gstep)
                 elif rec.kind == "inact":
                     def step(a=a):
-                        ops.instnorm_fwd(a["y"].act, a["stats"], a["out"].act, a["slope"],
-                                         a["res"].act if a["res"] is not None else None, a["eps"])
+                        res = a["res"].act if a["res"] is not None else None
+                        if a.get("stats_done"):       # the producing conv left (mean, rstd) behind
+                            ops.instnorm_act_fwd(a["y"].act, a["stats"], a["out"].act, a["slope"], res)
+                        else:
+                            ops.instnorm_fwd(a["y"].act, a["stats"], a["out"].act, a["slope"], res, a["eps"])
                     f.append(step)
                 elif rec.kind == "pool":
                     f.append(lambda a=a: ops.avgpool_fwd(a["x"].act, a["y"].act, a["stride"]))

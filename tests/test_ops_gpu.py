@@ -283,3 +283,30 @@ def test_error_paths(ops):
         ops.conv3d_fwd(x, w, None, y, (3, 3, 3), (1, 1, 1))
     with pytest.raises(RxError):
         ops.avgpool_fwd(y, y, (2, 2, 2))                    # geometry mismatch
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("case", [
+    (32, 32, (30, 36, 64)),      # conv_halo32p: statistics from the conv epilogue (ragged z / y tiles)
+    (64, 64, (14, 32, 64)),      # conv_halo64ws: same, 64-channel block
+    (64, 128, (8, 16, 32)),      # two channel blocks share the tiles
+    (32, 64, (6, 10, 12)),       # not a persistent-kernel layer: conv followed by the separate statistics pass
+])
+def test_conv3d_fwd_stats(ops, dtype, case):
+    """rx_conv3d_fwd_stats == rx_conv3d_fwd + rx_instnorm_stats: same y bit for bit, same (mean, rstd) to fp32 round-off"""
+    ci, co, dims = case
+    n = 3 if dims[0] == 30 else 2
+    x = to_act(ops, rnd((n, ci, *dims), dtype, seed=3), dtype)
+    w = rnd((co, ci, 3, 3, 3), torch.float32, seed=4, scale=0.1).float().cuda()
+    b = rnd((co,), torch.float32, seed=5).float().cuda()
+    wf, _ = ops.pack_conv_weight(w, dtype)
+    y1, y2 = ops.Act.empty(n, *dims, co, dtype), ops.Act.empty(n, *dims, co, dtype)
+    s1 = torch.empty((n, co, 2), device="cuda")
+    s2 = torch.empty((n, co, 2), device="cuda")
+    k, s = (3, 3, 3), (1, 1, 1)
+    ops.conv3d_fwd(x, wf, b, y1, k, s)
+    ops.instnorm_stats(y1, s1)
+    ops.conv3d_fwd_stats(x, wf, b, y2, k, s, s2)
+    torch.cuda.synchronize()
+    assert torch.equal(y1.t, y2.t)
+    assert torch.allclose(s1, s2, rtol=2e-5, atol=2e-6), (s1 - s2).abs().max()
