@@ -149,6 +149,11 @@ int rx_instnorm_gate_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, cons
 
 /* ---- nn.AvgPool3d(kernel=stride, per axis in {1,2}) (resblocks.py:95) -------------------- */
 int rx_avgpool_fwd(rx_dtype dt, const rx_act* x, const rx_act* y, const int32_t stride[3], void* stream);
+/* rx_instnorm_act_fwd and rx_avgpool_fwd of its output in one pass (the last block of an encoder stage feeds the AvgPool of
+ * the next stage's skip path, resblocks.py:95): out as above, pooled = avgpool(out), bit-identical to the two calls */
+int rx_instnorm_act_pool_fwd(rx_dtype dt, const rx_act* y, const float* stats, const rx_act* residual,
+                             const rx_act* out, const rx_act* pooled, const int32_t stride[3], float slope,
+                             void* stream);
 int rx_avgpool_bwd(rx_dtype dt, const rx_act* dy, const rx_act* dx, const int32_t stride[3], int accumulate,
                    void* stream);
 

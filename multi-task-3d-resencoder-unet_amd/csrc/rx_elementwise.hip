@@ -820,6 +820,88 @@ extern "C" int rx_avgpool_fwd(rx_dtype dt, const rx_act* x, const rx_act* y, con
   return RX_OK;
 }
 
+// ---- block epilogue + the AvgPool of the next block's skip path in ONE pass -----------------------------------------------
+// out = lrelu((y-mean)*rstd + res) and pooled = avgpool(out): a thread owns one POOLED voxel's channel vector, produces the
+// fz*fy*fx outputs under it and averages them as stored (same values, same summation order as avgpool_fwd_kernel reading
+// `out` back -- which moves the whole tensor through HBM a second time).
+template <typename T, bool HAS_RES>
+__global__ __launch_bounds__(256) void in_act_pool_fwd_kernel(const T* __restrict__ y, int ldy, long sy, const float* __restrict__ stats,
+                                                              const T* __restrict__ res, int ldr, long sr, T* __restrict__ out, int ldo, long so,
+                                                              T* __restrict__ pooled, int ldp, long sp, int Zo, int Yo, int Xo, int Yi, int Xi,
+                                                              int C, int fz, int fy, int fx, float slope) {
+  constexpr int P = Elem<T>::PER16;
+  const int CV = C / P, n = blockIdx.y;
+  const long total = (long)Zo * Yo * Xo * CV, step = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int cv = (int)(i % CV);
+  float mean[P], rstd[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    mean[j] = stats[2 * ((size_t)n * C + cv * P + j)];
+    rstd[j] = stats[2 * ((size_t)n * C + cv * P + j) + 1];
+  }
+  const float inv = 1.f / (float)(fz * fy * fx);
+  for (; i < total; i += step) {
+    const long vo = i / CV;
+    const int xo = (int)(vo % Xo), yo = (int)((vo / Xo) % Yo), zo = (int)(vo / ((long)Xo * Yo));
+    float acc[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) acc[j] = 0.f;
+    for (int a = 0; a < fz; ++a)
+      for (int b = 0; b < fy; ++b)
+        for (int c = 0; c < fx; ++c) {
+          const long vi = ((long)(zo * fz + a) * Yi + (yo * fy + b)) * Xi + (xo * fx + c);
+          Vec16<T> t = ld16(y + n * sy + vi * ldy + cv * P), r, o;
+          if (HAS_RES) r = ld16(res + n * sr + vi * ldr + cv * P);
+#pragma unroll
+          for (int j = 0; j < P; ++j) {
+            float f = (Elem<T>::to_f(t.v[j]) - mean[j]) * rstd[j];
+            if (HAS_RES) f += Elem<T>::to_f(r.v[j]);
+            f = f > 0.f ? f : f * slope;
+            o.v[j] = Elem<T>::from_f(f);
+            acc[j] += Elem<T>::to_f(o.v[j]);
+          }
+          st16(out + n * so + vi * ldo + cv * P, o);
+        }
+    Vec16<T> p;
+#pragma unroll
+    for (int j = 0; j < P; ++j) p.v[j] = Elem<T>::from_f(acc[j] * inv);
+    st16(pooled + n * sp + vo * ldp + cv * P, p);
+  }
+}
+
+extern "C" int rx_instnorm_act_pool_fwd(rx_dtype dt, const rx_act* y, const float* stats, const rx_act* residual, const rx_act* out,
+                                        const rx_act* pooled, const int32_t stride[3], float slope, void* stream) {
+  int rc;
+  if ((rc = check_vec_channels(y, dt, "rx_instnorm_act_pool_fwd(y)"))) return rc;
+  if ((rc = check_vec_channels(out, dt, "rx_instnorm_act_pool_fwd(out)"))) return rc;
+  if ((rc = check_vec_channels(pooled, dt, "rx_instnorm_act_pool_fwd(pooled)"))) return rc;
+  if (!stats || !same_geom(y, out)) RX_FAIL(RX_EINVAL, "rx_instnorm_act_pool_fwd: geometry mismatch / null stats");
+  if ((rc = check_pool(out, pooled, stride, "rx_instnorm_act_pool_fwd"))) return rc;
+  if (residual) {
+    if ((rc = check_vec_channels(residual, dt, "rx_instnorm_act_pool_fwd(residual)"))) return rc;
+    if (!same_geom(y, residual)) RX_FAIL(RX_EINVAL, "rx_instnorm_act_pool_fwd: residual geometry mismatch");
+  }
+  const long V = rx_act_voxels(y), Vp = rx_act_voxels(pooled);
+  hipStream_t st = (hipStream_t)stream;
+  RX_DISPATCH_DTYPE(dt, T, {
+    constexpr int P = Elem<T>::PER16;
+    const int CV = y->c / P;
+    const int G = sweep_grid(Vp * CV * 4, CV);      // a thread produces up to 8 outputs: 4x the blocks of a plain sweep of Vp
+    if (residual)
+      hipLaunchKernelGGL((in_act_pool_fwd_kernel<T, true>), dim3(G, y->n), dim3(256), 0, st, (const T*)y->ptr, y->ld, V * y->ld, stats,
+                         (const T*)residual->ptr, residual->ld, V * residual->ld, (T*)out->ptr, out->ld, V * out->ld, (T*)pooled->ptr,
+                         pooled->ld, Vp * pooled->ld, pooled->z, pooled->y, pooled->x, y->y, y->x, y->c, stride[0], stride[1], stride[2],
+                         slope);
+    else
+      hipLaunchKernelGGL((in_act_pool_fwd_kernel<T, false>), dim3(G, y->n), dim3(256), 0, st, (const T*)y->ptr, y->ld, V * y->ld, stats,
+                         (const T*)nullptr, 0, 0L, (T*)out->ptr, out->ld, V * out->ld, (T*)pooled->ptr, pooled->ld, Vp * pooled->ld,
+                         pooled->z, pooled->y, pooled->x, y->y, y->x, y->c, stride[0], stride[1], stride[2], slope);
+  });
+  RX_CHECK_LAUNCH("rx_instnorm_act_pool_fwd");
+  return RX_OK;
+}
+
 extern "C" int rx_avgpool_bwd(rx_dtype dt, const rx_act* dy, const rx_act* dx, const int32_t stride[3], int accumulate,
                               void* stream) {
   int rc;
@@ -1131,6 +1213,9 @@ static int check_kernel13(const int32_t k[3], const char* who) {
   return RX_OK;
 }
 
+int rx_stem_fwd_mfma_try(rx_dtype dt, const float* x, int n, int cin, int z, int y, int xx, const float* w, const float* bias,
+                         const rx_act* out, const int32_t kernel[3], hipStream_t st);
+
 extern "C" int rx_stem_conv_fwd(rx_dtype dt, const float* x_ncdhw, int n, int cin, int z, int y, int x, const float* w,
                                 const float* bias, const rx_act* out, const int32_t kernel[3], void* stream) {
   int rc;
@@ -1140,6 +1225,17 @@ extern "C" int rx_stem_conv_fwd(rx_dtype dt, const float* x_ncdhw, int n, int ci
   if (out->n != n || out->z != z || out->y != y || out->x != x) RX_FAIL(RX_EINVAL, "rx_stem_conv_fwd: geometry mismatch");
   hipStream_t st = (hipStream_t)stream;
   const int TT = kernel[0] * kernel[1] * kernel[2];
+  {
+    static int mf = -1;      // RX_STEM_MFMA=0: the VALU kernels below
+    if (mf < 0) {
+      const char* e = getenv("RX_STEM_MFMA");
+      mf = e ? atoi(e) : 1;
+    }
+    if (mf && rx_stem_fwd_mfma_try(dt, x_ncdhw, n, cin, z, y, x, w, bias, out, kernel, st) == 1) {
+      RX_CHECK_LAUNCH("rx_stem_conv_fwd(mfma)");
+      return RX_OK;
+    }
+  }
   if (dt != RX_F32 && out->c % 32 == 0 && (out->c * 4) % 16 == 0 && !getenv("RX_NO_STEM32")) {   // one thread per voxel x 32 channels
     const long V = rx_act_voxels(out);
     const int G = (int)((V + 255) / 256 > 16384 ? 16384 : (V + 255) / 256);

@@ -1,4 +1,4 @@
-// rx_stem_wgrad.hip -- weight gradient of the stem convolution (Cin <= 4 input channels, NCDHW fp32 image) on MFMA,
+// rx_stem_wgrad.hip -- forward (stem_fwd_mfma_kernel, end of file) and weight gradient of the stem convolution (Cin <= 4 input channels, NCDHW fp32 image) on MFMA,
 // 16-bit compute types:   dW[co][ci][t] = sum_v dY[v][co] * x[ci][v + t - 1]
 //
 // GEMM view: M = Cout (32-row blocks), N = 27 taps (padded to 32 columns), K = voxels.  A = dY^T comes from the
@@ -175,5 +175,151 @@ int rx_stem_wgrad_mfma_try(rx_dtype dt, const float* x, int n, int cin, int z, i
   }
 #undef RX_SW
   *nblocks_out = blocks;
+  return 1;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stem FORWARD on MFMA (16-bit compute types, Cout = 32):  out[v][co] = bias[co] + sum_k W[co][k] * X[k][v],  k = (ci, tap).
+// The VALU kernel (rx_elementwise.hip: one thread per voxel, 864 FMAs and 216 LDS broadcast reads per voxel) runs at ~200 us
+// for the cfg2 stem although it only has to write 268 MB; here a 32-voxel block is two MFMAs (K = 27 padded to 32 for one
+// input channel): A = the weights, converted once per workgroup and kept in registers; B = 8 consecutive k of the lane's voxel
+// gathered from the fp32 halo tile in LDS (tap offsets from a small LDS table) and converted in registers.  Tile 4x4x16.
+// ---------------------------------------------------------------------------------------------------------------------
+#define RX_STEM_NOTAP 0x40000000
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restrict__ x, int Cin, int N, int Z, int Y, int X,
+                                                            const float* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
+                                                            int ldo, long so, int kz, int ky, int kx, int tiles_per_block) {
+  constexpr int TZ = 4, TY = 4, TX = 16, HY = TY + 2, HX = TX + 2, HV = (TZ + 2) * HY * HX;  // 648
+  constexpr int XP = (HV + 255) / 256;
+  __shared__ float sX[4][HV + 8];
+  __shared__ int sOff[128];                       // k -> ci * (HV + 8) + tap offset inside the halo tile, or RX_STEM_NOTAP
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int TT = kz * ky * kx, K = Cin * TT, KS = (K + 15) / 16;
+  const int pz = (kz - 1) / 2, py = (ky - 1) / 2, px = (kx - 1) / 2;
+  const int tz_n = (Z + TZ - 1) / TZ, ty_n = (Y + TY - 1) / TY, tx_n = (X + TX - 1) / TX;
+  const int NT = N * tz_n * ty_n * tx_n;
+  const int t_begin = blockIdx.x * tiles_per_block, t_end = min(NT, t_begin + tiles_per_block);
+  const long V = (long)Z * Y * X;
+  if (tid < 128) {
+    int o = RX_STEM_NOTAP;
+    if (tid < K) {
+      const int ci = tid / TT, t = tid - ci * TT;
+      const int a = t / (ky * kx), b = (t / kx) % ky, c = t % kx;
+      o = ci * (HV + 8) + ((a - pz) * HY + (b - py)) * HX + (c - px);
+    }
+    sOff[tid] = o;
+  }
+  // halo element(s) of this thread: (hz, hy, hx) packed, decoded once
+  int hh[XP];
+#pragma unroll
+  for (int p = 0; p < XP; ++p) {
+    const int i = tid + 256 * p;
+    const int hx = i % HX, t = i / HX;
+    hh[p] = i < HV ? ((t / HY) << 16) | ((t % HY) << 8) | hx : -1;
+  }
+  // A fragments: lane (co = lane & 31, k-half = lane >> 5) holds W[co][ks*16 + 8*h .. +7]   (w is (32, Cin, TT) = [co][k])
+  const int fr = lane & 31, fh = lane >> 5;
+  u32x4 af[7];
+#pragma unroll
+  for (int ks = 0; ks < 7; ++ks) {
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = ks * 16 + fh * 8 + j;
+      f[j] = (ks < KS && k < K) ? w[(long)fr * K + k] : 0.f;
+    }
+    af[ks] = pack8<T>(f);
+  }
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bv[r] = bias ? bias[8 * (r >> 2) + 4 * fh + (r & 3)] : 0.f;
+  float xq[4][XP];
+  auto prefetch = [&](int tile) {
+    const int tx = tile % tx_n, t1 = tile / tx_n, ty = t1 % ty_n, t2 = t1 / ty_n, tz = t2 % tz_n, n = t2 / tz_n;
+    const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+      if (ci < Cin) {
+        const float* xc = x + ((long)n * Cin + ci) * V;
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+          const int z = z0 + (hh[p] >> 16) - 1, y = y0 + ((hh[p] >> 8) & 255) - 1, xx = x0 + (hh[p] & 255) - 1;
+          float v = 0.f;
+          if (hh[p] >= 0 && (unsigned)z < (unsigned)Z && (unsigned)y < (unsigned)Y && (unsigned)xx < (unsigned)X) v = xc[((long)z * Y + y) * X + xx];
+          xq[ci][p] = v;
+        }
+      }
+  };
+  if (t_begin < t_end) prefetch(t_begin);
+  const float* sx0 = &sX[0][0];
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();                               // previous tile's operand reads are done
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+      if (ci < Cin)
+#pragma unroll
+        for (int p = 0; p < XP; ++p)
+          if (hh[p] >= 0) sX[ci][tid + 256 * p] = xq[ci][p];
+    __syncthreads();
+    if (tile + 1 < t_end) prefetch(tile + 1);
+    const int tx = tile % tx_n, t1 = tile / tx_n, ty = t1 % ty_n, t2 = t1 / ty_n, tz = t2 % tz_n, n = t2 / tz_n;
+    const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int v = (wave * 2 + b) * 32 + fr;      // this lane's voxel (the accumulator column)
+      const int vx = v & 15, vy = (v >> 4) & 3, vz = v >> 6;
+      const int centre = ((vz + 1) * HY + (vy + 1)) * HX + vx + 1;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = bv[r];
+#pragma unroll
+      for (int ks = 0; ks < 7; ++ks) {
+        if (ks < KS) {
+          float f[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int o = sOff[ks * 16 + fh * 8 + j];
+            f[j] = o != RX_STEM_NOTAP ? sx0[centre + o] : 0.f;
+          }
+          Mma<T>::run(acc, af[ks], pack8<T>(f));
+        }
+      }
+      const int z = z0 + vz, y = y0 + vy, xx = x0 + vx;
+      if (z >= Z || y >= Y || xx >= X) continue;
+      T* op = out + n * so + ((long)(z * Y + y) * X + xx) * ldo;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        T vals[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vals[i] = Elem<T>::from_f(acc[4 * g4 + i]);
+        *reinterpret_cast<u32x2*>(op + 8 * g4 + 4 * fh) = *reinterpret_cast<u32x2*>(vals);
+      }
+    }
+  }
+}
+
+// returns 1 if handled (16-bit dtypes, Cout == 32, Cin * taps <= 112), 0 otherwise
+int rx_stem_fwd_mfma_try(rx_dtype dt, const float* x, int n, int cin, int z, int y, int xx, const float* w, const float* bias,
+                         const rx_act* out, const int32_t kernel[3], hipStream_t st) {
+  const int K = cin * kernel[0] * kernel[1] * kernel[2];
+  if (dt == RX_F32 || out->c != 32 || out->ld % 4 || ((uintptr_t)out->ptr & 7) || K > 112) return 0;
+  const int NT = n * ((z + 3) / 4) * ((y + 3) / 4) * ((xx + 15) / 16);
+  static int maxb = -1;
+  if (maxb < 0) {
+    const char* e = getenv("RX_STEM_BLOCKS");
+    maxb = e ? atoi(e) : 1024;   // measured: 512 -> 162 us, 768 -> 131, 1024 -> 119, 1280 -> 147, 2048 -> 127, one tile per workgroup -> 193
+  }
+  int blocks = NT < maxb ? NT : maxb;       // 4 resident workgroups per CU, the weights / tap table are set up once per workgroup
+  const int per = (NT + blocks - 1) / blocks;
+  blocks = (NT + per - 1) / per;
+  const long so = rx_act_voxels(out) * (long)out->ld;
+  if (dt == RX_BF16)
+    hipLaunchKernelGGL((stem_fwd_mfma_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, x, cin, n, z, y, xx, w, bias, (bf16_t*)out->ptr, out->ld, so,
+                       kernel[0], kernel[1], kernel[2], per);
+  else
+    hipLaunchKernelGGL((stem_fwd_mfma_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, x, cin, n, z, y, xx, w, bias, (f16_t*)out->ptr, out->ld, so,
+                       kernel[0], kernel[1], kernel[2], per);
   return 1;
 }

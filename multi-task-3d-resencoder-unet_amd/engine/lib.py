@@ -67,6 +67,7 @@ _SIGNATURES = {
     "rx_instnorm_gate_act_bwd": (c_int, [c_int, _P, _P, c_void_p, _P, c_float, c_void_p, c_void_p, c_void_p, c_int, _P, _P,
                                          c_int, c_void_p]),
     "rx_avgpool_fwd": (c_int, [c_int, _P, _P, I3, c_void_p]),
+    "rx_instnorm_act_pool_fwd": (c_int, [c_int, _P, c_void_p, _P, _P, _P, I3, c_float, c_void_p]),
     "rx_avgpool_bwd": (c_int, [c_int, _P, _P, I3, c_int, c_void_p]),
     "rx_stem_conv_fwd": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, _P, I3,
                                  c_void_p]),

@@ -311,6 +311,12 @@ def avgpool_fwd(x, y, stride):
           "rx_avgpool_fwd")
 
 
+def instnorm_act_pool_fwd(y, stats, out, pooled, stride, slope=0.01, residual=None):
+    check(load().rx_instnorm_act_pool_fwd(_code(y.dtype), byref(y.desc()), _ptr(stats),
+                                          byref(residual.desc()) if residual is not None else None, byref(out.desc()),
+                                          byref(pooled.desc()), I3(*stride), float(slope), stream_ptr()), "rx_instnorm_act_pool_fwd")
+
+
 def avgpool_bwd(dy, dx, stride, accumulate=False):
     check(load().rx_avgpool_bwd(_code(dy.dtype), byref(dy.desc()), byref(dx.desc()), I3(*stride), int(accumulate),
                                 stream_ptr()), "rx_avgpool_bwd")

@@ -20,6 +20,8 @@ Layout decisions:
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional
 
+import os
+
 import torch
 from torch import nn
 
@@ -419,6 +421,16 @@ class Plan:
                         and rec.a["y"].act.voxels > 512 and rec.a["y"].act.dims[3] >= 16):
                     rec.a["stats_to"] = nxt.a
                     nxt.a["stats_done"] = True
+            # block output -> AvgPool of the next block's skip path: one pass (rx_instnorm_act_pool_fwd) above the size the
+            # single-launch InstanceNorm kernel takes
+            producers = {id(r.a["out"]): r for r in tape if r.kind == "inact" and r.a["gate"] is None}
+            for rec in tape:
+                if (rec.kind == "pool" and id(rec.a["x"]) in producers and rec.a["x"].act.voxels > 512
+                        and os.environ.get("RX_FUSED_POOL", "1") != "0"):
+                    src = producers[id(rec.a["x"])]
+                    if "pool_to" not in src.a:
+                        src.a["pool_to"] = rec.a
+                        rec.a["fused"] = True
             for rec in tape:
                 a = rec.a
                 if rec.kind == "stem":
@@ -455,13 +467,19 @@ class Plan:
                 elif rec.kind == "inact":
                     def step(a=a):
                         res = a["res"].act if a["res"] is not None else None
-                        if a.get("stats_done"):       # the producing conv left (mean, rstd) behind
+                        pool = a.get("pool_to")
+                        if pool is not None:
+                            if not a.get("stats_done"):
+                                ops.instnorm_stats(a["y"].act, a["stats"], a["eps"])
+                            ops.instnorm_act_pool_fwd(a["y"].act, a["stats"], a["out"].act, pool["y"].act, pool["stride"], a["slope"], res)
+                        elif a.get("stats_done"):     # the producing conv left (mean, rstd) behind
                             ops.instnorm_act_fwd(a["y"].act, a["stats"], a["out"].act, a["slope"], res)
                         else:
                             ops.instnorm_fwd(a["y"].act, a["stats"], a["out"].act, a["slope"], res, a["eps"])
                     f.append(step)
                 elif rec.kind == "pool":
-                    f.append(lambda a=a: ops.avgpool_fwd(a["x"].act, a["y"].act, a["stride"]))
+                    if not a.get("fused"):
+                        f.append(lambda a=a: ops.avgpool_fwd(a["x"].act, a["y"].act, a["stride"]))
                 elif rec.kind == "copy":
                     f.append(lambda a=a: ops.avgpool_fwd(a["x"].act, a["y"].act, (1, 1, 1)))
                 elif rec.kind == "head":

@@ -310,3 +310,21 @@ def test_conv3d_fwd_stats(ops, dtype, case):
     torch.cuda.synchronize()
     assert torch.equal(y1.t, y2.t)
     assert torch.allclose(s1, s2, rtol=2e-5, atol=2e-6), (s1 - s2).abs().max()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("stride", [(2, 2, 2), (1, 2, 2)])
+def test_instnorm_act_pool_fwd_is_the_two_calls(ops, dtype, stride):
+    n, c, dims = 2, 32, (8, 12, 20)
+    y = to_act(ops, rnd((n, c, *dims), dtype, seed=1), dtype)
+    res = to_act(ops, rnd((n, c, *dims), dtype, seed=2), dtype, ld=64, c0=32)        # residual inside a wider buffer
+    stats = torch.empty((n, c, 2), device="cuda")
+    ops.instnorm_stats(y, stats)
+    pd = tuple(d // s for d, s in zip(dims, stride))
+    o1, o2 = ops.Act.empty(n, *dims, c, dtype), ops.Act.empty(n, *dims, c, dtype)
+    p1, p2 = ops.Act.empty(n, *pd, c, dtype), ops.Act.empty(n, *pd, c, dtype)
+    ops.instnorm_act_fwd(y, stats, o1, 0.01, res)
+    ops.avgpool_fwd(o1, p1, stride)
+    ops.instnorm_act_pool_fwd(y, stats, o2, p2, stride, 0.01, res)
+    torch.cuda.synchronize()
+    assert torch.equal(o1.t, o2.t) and torch.equal(p1.t, p2.t)
