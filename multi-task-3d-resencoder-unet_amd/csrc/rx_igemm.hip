@@ -408,7 +408,12 @@ static int igemm_launch(rx_dtype dt, const void* in, const void* w, const float*
       const int mtiles = (int)((NV + 127) / 128);
       const int nsteps = g.ph[0].ntaps * (g.Ci / KE);
       const long base_wgs = (long)mtiles * (g.Co / 64);
-      int ks = (int)((512 + base_wgs - 1) / base_wgs);
+      static int fat_wgs = -1;
+      if (fat_wgs < 0) {
+        const char* e = getenv("RX_FAT_WGS");
+        fat_wgs = e ? atoi(e) : 512;
+      }
+      int ks = (int)((fat_wgs + base_wgs - 1) / base_wgs);
       if (ks > nsteps / 4) ks = nsteps / 4;   // >= 4 K steps per workgroup; also bounds the serial sum of the reduce
       if (ks < 1) ks = 1;
       while (ks > 1 && (size_t)ks * NV * g.Co * sizeof(float) > ws_bytes) --ks;
