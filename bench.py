@@ -71,7 +71,8 @@ def pmc_traffic(kernel_label):
     args = base.split("<")[1].rstrip(">").split(",") if "<" in base else []
     want = "".join(f"Li{a}E" for a in args)
     for k, v in data.items():
-        if name in k and "DF16b" in k and want in k:
+        # (rocprofv3 prints kernels with bool template arguments demangled, and garbles __bf16 into "bool _Accum")
+        if name in k and ("DF16b" in k or "_Accum" in k) and want in k:
             return dict(bytes_per_launch=v["read_bytes_per_launch"] + v["write_bytes_per_launch"],
                         read=v["read_bytes_per_launch"], write=v["write_bytes_per_launch"], source=os.path.basename(files[-1]))
     return None

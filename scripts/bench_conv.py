@@ -21,7 +21,7 @@ flt = [a for a in sys.argv[1:] if not a.startswith("--") and not a.isdigit()]
 iters = 10
 if "--iters" in sys.argv:
     iters = int(sys.argv[sys.argv.index("--iters") + 1])
-KINDS = ("fwd", "fwdst", "dgrad", "wgrad")      # fwdst: conv + InstanceNorm statistics (rx_conv3d_fwd_stats)
+KINDS = ("fwd", "fwdst", "dgrad", "dgradacc", "wgrad")   # dgradacc: dx += (accumulate)      # fwdst: conv + InstanceNorm statistics (rx_conv3d_fwd_stats)
 kinds = [f for f in flt if f in KINDS] or ["fwd", "dgrad", "wgrad"]
 names = [f for f in flt if f not in KINDS]
 dt = torch.bfloat16
@@ -37,7 +37,7 @@ for name, ci, co, dims, n in SHAPES:
     k, s = (3, 3, 3), (1, 1, 1)
     flops = 2.0 * n * dims[0] * dims[1] * dims[2] * ci * co * 27
     stats = torch.empty((n, co, 2), device="cuda")
-    fns = {"fwd": lambda: ops.conv3d_fwd(x, wf, None, y, k, s), "fwdst": lambda: ops.conv3d_fwd_stats(x, wf, None, y, k, s, stats), "dgrad": lambda: ops.conv3d_bwd_data(y, wb, dx, k, s),
+    fns = {"fwd": lambda: ops.conv3d_fwd(x, wf, None, y, k, s), "fwdst": lambda: ops.conv3d_fwd_stats(x, wf, None, y, k, s, stats), "dgrad": lambda: ops.conv3d_bwd_data(y, wb, dx, k, s), "dgradacc": lambda: ops.conv3d_bwd_data(y, wb, dx, k, s, True),
            "wgrad": lambda: ops.conv3d_bwd_weight(x, y, dw, k, s)}
     for kind in kinds:
         fn = fns[kind]
