@@ -1181,7 +1181,7 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   }
   int BN = (g.Co % 64 == 0) ? 64 : 32;
   if (BN == 64 && (long)g.NT * (g.Co / 64) < 256) BN = 32;  // under-filled grid: twice the workgroups, half the work each
-  if ((long)g.NT * (g.Co / BN) < 128) {
+  if ((long)g.NT * (g.Co / BN) < 192) {     // (128 pairs -- the 1024-channel data gradient of the first decoder conv at 8^3 -- measured 93 us here, ~60 us on igemm_fat)
     // too few (tile, channel block) pairs to fill 256 CUs: split the input channels over blockIdx.z, fp32 slabs + a
     // fixed-order reduce.  Against the split-K gather kernel (igemm_fat) the activations are staged ONCE per chunk with
     // their halo instead of once per tap -- that kernel moves 340 MB through L2 for a 512->512 layer at 8^3 (216 MB of
