@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void ch_splitk_reduce(const float* __restrict_
 // lane_base + CONSTANT and folds into the ds_read_b128 offset field -- no address arithmetic in the MFMA loop
 // (the generic kernel above spends ~14 VALU instructions per MFMA on XOR-swizzled addresses).
 // ---------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool FLIP>
 __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
                                                              T* __restrict__ out, const ConvHaloGeom g) {
   constexpr int P = Elem<T>::PER16;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict
 #pragma unroll
       for (int p = 0; p < XPIECES; ++p) {
         u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (xoff[p] >= 0 && !(g.dbg & 1)) v = *reinterpret_cast<const u32x4*>(in_n + xoff[p] + cc * KB);
+        if (xoff[p] >= 0 && !RX_ABLATE(g, 1)) v = *reinterpret_cast<const u32x4*>(in_n + xoff[p] + cc * KB);
         xr[p] = v;
       }
     }
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict
     for (int p = 0; p < WPIECES; ++p) {
       const int i = tid + 256 * p;
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (i < 9 * 32 * 4 && !(g.dbg & 2)) {
+      if (i < 9 * 32 * 4 && !RX_ABLATE(g, 2)) {
         const int c4 = i & 3, r = (i >> 2) & 31, tl = i >> 7;
         v = *reinterpret_cast<const u32x4*>(w + ((long)(9 * dzg + tl) * g.Co + n0 + r) * g.Ci + cc * KB + c4 * P);
       }
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict
   const int wsw = (fr >> 2) & 3;                         // weight-row swizzle term of this lane
   const unsigned char* wb0 = sW + fr * 64 + (((0 + fh) ^ wsw) << 4);  // k-step 0
   const unsigned char* wb1 = sW + fr * 64 + (((2 + fh) ^ wsw) << 4);  // k-step 1
-  const int sgn = g.flip ? -1 : 1;
+  constexpr int sgn = FLIP ? -1 : 1;                   // compile-time: the tap offsets stay ds_read immediates
 
   f32x16 acc[2];
 #pragma unroll
@@ -354,10 +354,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict
     const int dzoff = sgn * ((ph % 3) - 1) * (HY * HX * ROWB);  // wave-uniform byte offset of this dz plane
     const unsigned char* x0p = xb[0] + dzoff;
     const unsigned char* x1p = xb[1] + dzoff;
-    if (!(g.dbg & 4)) {
+    if (!RX_ABLATE(g, 4)) {
       // 18 steps (9 taps x 2 k-steps), software pipelined by hand: the three fragment reads of step i+1 are issued
       // before the two MFMAs of step i; sched_group_barrier pins the 2-MFMA / 3-DS_READ interleave.
-      const int ssg = sgn;
+      constexpr int ssg = sgn;
       u32x4 fa[2], f0[2], f1[2];
       auto ld = [&](int i, int slot) {
         const int tl = i >> 1, ks = i & 1;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict
   for (int b = 0; b < 2; ++b) {
     const int v = (wave * 2 + b) * 32 + fv;
     const int z = z0 + (v >> 6), y = y0 + ((v >> 4) & 3), x = x0 + (v & 15);
-    if (z >= g.Z || y >= g.Y || x >= g.X || (g.dbg & 8)) continue;
+    if (z >= g.Z || y >= g.Y || x >= g.X || RX_ABLATE(g, 8)) continue;
     T* op = out + (long)n * g.out_ss + ((long)(z * g.Y + y) * g.X + x) * g.ldo + n0;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
@@ -459,7 +459,7 @@ __device__ inline void ch_stat_flush(float (&s1)[NA][16], float (&s2)[NA][16], f
 // STATS: forward instantiation that accumulates the InstanceNorm statistics of its output; ACC: dx += (old values prefetched
 // under the MFMA loop).  Compile-time so that the plain variant keeps its 103 registers: with run-time flags the statistics
 // code alone cost every launch 10-17 % (306 -> 358 us for the 32 -> 32 data gradient @128^3).
-template <typename T, bool STATS = false, bool ACC = false>
+template <typename T, bool STATS = false, bool ACC = false, bool FLIP = false>
 __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
                                                               T* __restrict__ out, const ConvHaloGeom g, int tiles_per_wg) {
   constexpr int P = Elem<T>::PER16;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
         u32x4 v = u32x4{0u, 0u, 0u, 0u};
         if (xh[p] >= 0) {
           const int z = z0 + (xh[p] >> 16) - 1, y = y0 + ((xh[p] >> 8) & 255) - 1, x = x0 + (xh[p] & 255) - 1;
-          if ((unsigned)z < (unsigned)g.Z && (unsigned)y < (unsigned)g.Y && (unsigned)x < (unsigned)g.X && !(g.dbg & 1))
+          if ((unsigned)z < (unsigned)g.Z && (unsigned)y < (unsigned)g.Y && (unsigned)x < (unsigned)g.X && !RX_ABLATE(g, 1))
             v = *reinterpret_cast<const u32x4*>(in_n + ((long)(z * g.Y + y) * g.X + x) * g.ldi);
         }
         xr[p] = v;
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
     const int wsw = (fr >> 2) & 3;
     const unsigned char* wb0 = sW + fr * 64 + (((0 + fh) ^ wsw) << 4);
     const unsigned char* wb1 = sW + fr * 64 + (((2 + fh) ^ wsw) << 4);
-    const int sgn = g.flip ? -1 : 1;
+    constexpr int sgn = FLIP ? -1 : 1;                 // compile-time: the tap offsets stay ds_read immediates
     float s1[1][16], s2[1][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) s1[0][r] = 0.f, s2[0][r] = 0.f;
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-      if (!(g.dbg & 4))
+      if (!RX_ABLATE(g, 4))
 #pragma unroll
       for (int dzg = 0; dzg < 3; ++dzg) {
         const int dzoff = sgn * (dzg - 1) * (HY * HX * ROWB);
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
       for (int b = 0; b < 2; ++b) {
         const int v = (wave * 2 + b) * 32 + fv;
         const int z = z0 + (v >> 6), y = y0 + ((v >> 4) & 3), x = x0 + (v & 15);
-        if (z >= g.Z || y >= g.Y || x >= g.X || (g.dbg & 8)) continue;
+        if (z >= g.Z || y >= g.Y || x >= g.X || RX_ABLATE(g, 8)) continue;
         T* op = out + (long)n * g.out_ss + ((long)(z * g.Y + y) * g.X + x) * g.ldo;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -1064,9 +1064,11 @@ static void ch32p_launch(hipStream_t st, const void* in, const void* w, const fl
   const size_t lds = (size_t)CH32P_W_BYTES + 2 * (size_t)CH32P_HALO_BYTES;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32p_kernel<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32p_kernel<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32p_kernel<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32p_kernel<T, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32p_kernel<T, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32p_kernel<T, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32p_kernel<T, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32p_kernel<T, false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
   int wgs = g.NT < 256 ? g.NT : 256;                    // one persistent workgroup per CU
@@ -1076,12 +1078,13 @@ static void ch32p_launch(hipStream_t st, const void* in, const void* w, const fl
   wgs_s = (NTs + per - 1) / per;
   wgs = wgs_s * g.N;
   const_cast<ConvHaloGeom&>(g).wgs_s = wgs_s;
-  if (g.stat_part && !g.accumulate)
-    hipLaunchKernelGGL((conv_halo32p_kernel<T, true, false>), dim3(wgs), dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
-  else if (g.accumulate)
-    hipLaunchKernelGGL((conv_halo32p_kernel<T, false, true>), dim3(wgs), dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
-  else
-    hipLaunchKernelGGL((conv_halo32p_kernel<T, false, false>), dim3(wgs), dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
+#define RX_32P(S, A, F) hipLaunchKernelGGL((conv_halo32p_kernel<T, S, A, F>), dim3(wgs), dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per)
+  if (g.stat_part && !g.accumulate && !g.flip) RX_32P(true, false, false);
+  else if (g.flip && g.accumulate) RX_32P(false, true, true);
+  else if (g.flip) RX_32P(false, false, true);
+  else if (g.accumulate) RX_32P(false, true, false);
+  else RX_32P(false, false, false);
+#undef RX_32P
 }
 
 template <typename T>
@@ -1089,10 +1092,14 @@ static void ch32_launch(dim3 grid, hipStream_t st, const void* in, const void* w
   const size_t lds = (size_t)648 * 80 + (size_t)9 * 32 * 64;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((conv_halo32_kernel<T>), grid, dim3(256), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g);
+  if (g.flip)
+    hipLaunchKernelGGL((conv_halo32_kernel<T, true>), grid, dim3(256), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g);
+  else
+    hipLaunchKernelGGL((conv_halo32_kernel<T, false>), grid, dim3(256), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g);
 }
 
 static int ch_p2ceil(int v) {

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_halo16_kernel(const T* __restric
   auto run = [&](auto wc) {
     constexpr int W = decltype(wc)::value;
     for (int tile = t_begin; tile < t_end; ++tile) {
-      if (!(g.dbg & 1) || tile == t_begin) {
+      if (!RX_ABLATE(g, 1) || tile == t_begin) {
         __syncthreads();          // every wave is done reading the previous tile
         commit(0);
         __syncthreads();
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_halo16_kernel(const T* __restric
           for (int p = 0; p < 15; ++p) issue_piece(p);
         }
       }
-      if (!(g.dbg & 2)) wgh16_tile_mma<T, W>(gb, xb, acc, stage);
+      if (!RX_ABLATE(g, 2)) wgh16_tile_mma<T, W>(gb, xb, acc, stage);
     }
   };
   switch (wave) {   // scalar branch: the tap set of a wave is a compile-time constant inside each arm
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo16ws_kernel(const T* __restr
       for (int tile = t_begin; tile < t_end; ++tile) {
         const int buf = (tile - t_begin) & 1;
         const lds_byte* gb = (const lds_byte*)(smem) + buf * WGH16_BUF_BYTES + lane_off;
-        if (!(g.dbg & 2)) wgh16_tile_mma<T, W>(gb, gb + 256 * 64, acc, stage);
+        if (!RX_ABLATE(g, 2)) wgh16_tile_mma<T, W>(gb, gb + 256 * 64, acc, stage);
         __syncthreads();
       }
     };
