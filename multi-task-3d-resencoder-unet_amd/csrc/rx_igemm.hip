@@ -487,6 +487,8 @@ static int igemm_launch(rx_dtype dt, const void* in, const void* w, const float*
 // rx_conv_halo.hip
 int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* bias, const rx_act* out, int flip, int accumulate,
                      void* ws, size_t ws_bytes, hipStream_t st, float* stat_part, size_t stat_bytes, int* stat_chunks);
+// rx_dgrad_s2.hip
+int rx_dgrad_s2_halo_try(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx, int accumulate, hipStream_t st);
 // rx_elementwise.hip
 void rx_stats_finalize_launch(const float* partial, int N, int nchunks, int C, double V, float eps, float* stats, hipStream_t st);
 static bool is_333_s1(const int32_t k[3], const int32_t s[3]) {
@@ -585,6 +587,11 @@ extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_b
     RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_data: geometry mismatch");
   if (is_333_s1(kernel, stride)) {
     rc = rx_conv_halo_try(dt, dy, w_bwd, nullptr, dx, 1, accumulate, ws, wsb, (hipStream_t)stream, nullptr, 0, nullptr);
+    if (rc < 0) return rc;
+    if (rc == 1) return RX_OK;
+  }
+  if (kernel[0] == 3 && kernel[1] == 3 && kernel[2] == 3 && stride[0] == 2 && stride[1] == 2 && stride[2] == 2) {
+    rc = rx_dgrad_s2_halo_try(dt, dy, w_bwd, dx, accumulate, (hipStream_t)stream);   // LDS-halo kernel, all 8 parity classes
     if (rc < 0) return rc;
     if (rc == 1) return RX_OK;
   }

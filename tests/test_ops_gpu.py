@@ -57,6 +57,8 @@ CONV_CASES = [
     (512, 512, (3, 8, 8), (3, 3, 3), (1, 1, 1)),      # same, several (ragged) tiles per workgroup
     (32, 32, (30, 36, 64), (3, 3, 3), (1, 1, 1)),     # >= 512 tiles of 4x4x16: persistent weight-stationary kernel (ragged z/y)
     (64, 64, (14, 32, 64), (3, 3, 3), (1, 1, 1)),     # >= 256 tiles, 64 channels: wave-specialised producer/consumer kernel
+    (128, 64, (32, 32, 64), (3, 3, 3), (2, 2, 2)),    # stride-2 data gradient on the parity-class halo kernel (64 dY channels)
+    (128, 64, (24, 40, 72), (3, 3, 3), (2, 2, 2)),    # same, ragged dY tiles
 ]
 
 
