@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_halo_kernel(const T* __restri
 // (class structure, tap offsets and weight slots are compile-time).  290 us (gather kernel) -> 192 us (kernel above) -> 140 us;
 // -0.35 ms per cfg2 step.  Ablation (-DRX_ABLATION=1, RX_DBG): without halo loads 128 us, without MFMAs 144, without stores
 // 111, with none of the three 99 us -- the floor is the LDS operand traffic (every one of the 8 waves reads every weight
-// fragment: 1.7 MB per tile) plus the weight staging; next step: one parity class per wave with its weights in registers.
+// fragment: 1.7 MB per tile) plus the weight staging.  Tried: one parity class per wave with its weights as register-resident
+// A fragments (LDS then holds only the halo): 128 fragment registers + halo prefetch + accumulators do not fit 256 VGPRs (the
+// compiler spilled ~200 registers, 271 us) -- it needs the weight fragments in AGPRs by hand, not attempted.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ constexpr int DS2_SLOT_K[26] = {12, 14, 10, 16, 9, 11, 15, 17, 4, 22, 3, 5, 21, 23, 1, 7, 19, 25, 0, 2, 6, 8, 18, 20, 24, 26};
 __device__ constexpr int DS2_SLOT_OFF[26] = {1, 0, 17, 0, 18, 17, 1, 0, 85, 0, 86, 85, 1, 0, 102, 85, 17, 0, 103, 102, 86, 85, 18, 17, 1, 0};
