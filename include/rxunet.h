@@ -42,6 +42,12 @@ typedef enum { RX_ACT_NONE = 0, RX_ACT_SIGMOID = 1, RX_ACT_SOFTMAX = 2 } rx_head
 typedef struct {
   void* ptr;
   int32_t n, z, y, x, c, ld;
+  /* cs == 0: the c channels of a voxel are contiguous (stride ld between voxels).
+   * cs != 0 ("planar concat", only the 3x3x3 stride-1 conv entry points take it, 16-bit types, ld == 32): the channels come
+   * in groups of ld, group j of element (n,z,y,x) lives at ptr[j*cs + (((n*z_+z)*y_+y)*x_+x)*ld + c%ld] -- how the two
+   * 32-channel halves of the full-resolution decoder.py:147 concat stay DENSE tensors (a 64-byte channel slice of a 128-byte
+   * voxel costs every kernel that streams it 1.5-2x: measured 154 -> 250 us for the stride-2 conv reading it). */
+  int64_t cs;
 } rx_act;
 
 int rx_abi_version(void);

@@ -123,7 +123,13 @@ static inline size_t rx_align_up(size_t v, size_t a) { return (v + a - 1) / a * 
 
 static inline long rx_act_voxels(const rx_act* a) { return (long)a->z * a->y * a->x; }
 static inline bool rx_act_ok(const rx_act* a) {
-  return a && a->ptr && a->n > 0 && a->z > 0 && a->y > 0 && a->x > 0 && a->c > 0 && a->ld >= a->c;
+  return a && a->ptr && a->n > 0 && a->z > 0 && a->y > 0 && a->x > 0 && a->c > 0 && a->ld >= a->c && a->cs == 0;
+}
+// the same, or a planar concat of 32-channel groups (rx_act.cs): only the 3x3x3 stride-1 conv entry points accept it
+static inline bool rx_act_ok_planar(const rx_act* a) {
+  if (a && a->cs != 0)
+    return a->ptr && a->n > 0 && a->z > 0 && a->y > 0 && a->x > 0 && a->ld == 32 && a->c > 32 && a->c % 32 == 0 && a->cs > 0 && a->cs % 8 == 0;
+  return rx_act_ok(a);
 }
 
 // ---- tap tables and MFMA wrappers shared by the implicit-GEMM and weight-gradient kernels ------

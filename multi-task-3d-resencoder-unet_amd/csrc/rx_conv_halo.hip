@@ -20,6 +20,7 @@ struct ConvHaloGeom {
   int N, Z, Y, X;
   int Ci, Co, ldi, ldo;
   long in_ss, out_ss;
+  long in_cs, out_cs;         // element offset between consecutive 32-channel groups of in / out (planar concat: rx_act.cs)
   int TZ, TY, TX, lTX, lTY;
   int HY, HX, HV, VT;
   int tz_n, ty_n, tx_n, NT;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict
 #pragma unroll
       for (int p = 0; p < XPIECES; ++p) {
         u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (xoff[p] >= 0 && !RX_ABLATE(g, 1)) v = *reinterpret_cast<const u32x4*>(in_n + xoff[p] + cc * KB);
+        if (xoff[p] >= 0 && !RX_ABLATE(g, 1)) v = *reinterpret_cast<const u32x4*>(in_n + xoff[p] + cc * g.in_cs);
         xr[p] = v;
       }
     }
@@ -928,7 +929,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
 #pragma unroll
           for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) oldv[a][b][g4] = ok ? *reinterpret_cast<const u32x2*>(op + a * 32 + 8 * g4) : u32x2{0u, 0u};
+            for (int g4 = 0; g4 < 4; ++g4) oldv[a][b][g4] = ok ? *reinterpret_cast<const u32x2*>(op + a * g.out_cs + 8 * g4) : u32x2{0u, 0u};
         }
       }
 #pragma unroll
@@ -965,13 +966,14 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const int co = a * 32 + 8 * g4 + 4 * fh;
+            const long cm = a * g.out_cs + 8 * g4 + 4 * fh;    // memory offset of channel co (== co unless out is a planar concat)
             T vals[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               float f = acc[a][b][4 * g4 + i];
               if (bias) f += bias[n0 + co + i];
               if (ACC) f += Elem<T>::to_f(reinterpret_cast<const T*>(&oldv[a][b][g4])[i]);
-              else if (g.accumulate) f += Elem<T>::to_f(op[co + i]);
+              else if (g.accumulate) f += Elem<T>::to_f(op[cm + i]);
               vals[i] = Elem<T>::from_f(f);
               if (STATS) {
                 const float r = Elem<T>::to_f(vals[i]);
@@ -979,7 +981,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
                 s2[a][4 * g4 + i] += r * r;
               }
             }
-            *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
+            *reinterpret_cast<u32x2*>(op + cm) = *reinterpret_cast<u32x2*>(vals);
           }
       }
       lds_only_barrier();
@@ -1153,6 +1155,8 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   g.Ci = in->c, g.Co = out->c, g.ldi = in->ld, g.ldo = out->ld;
   g.in_ss = rx_act_voxels(in) * (long)in->ld;
   g.out_ss = rx_act_voxels(out) * (long)out->ld;
+  g.in_cs = in->cs ? in->cs : KB, g.out_cs = out->cs ? out->cs : 32;
+  if ((in->cs || out->cs) && dt == RX_F32) return 0;
   int TX = ch_p2ceil(g.X);
   TX = TX < 4 ? 4 : (TX > 16 ? 16 : TX);
   int rem = 256 / TX;
@@ -1188,6 +1192,7 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   }
   int BN = (g.Co % 64 == 0) ? 64 : 32;
   if (BN == 64 && (long)g.NT * (g.Co / 64) < 256) BN = 32;  // under-filled grid: twice the workgroups, half the work each
+  if ((in->cs || out->cs) && (long)g.NT * (g.Co / BN) < 192) RX_FAIL(RX_EUNSUPPORTED, "conv_halo: planar-concat operand on a layer too small for the halo kernels");
   if ((long)g.NT * (g.Co / BN) < 192) {     // (128 pairs -- the 1024-channel data gradient of the first decoder conv at 8^3 -- measured 93 us here, ~60 us on igemm_fat)
     // too few (tile, channel block) pairs to fill 256 CUs: split the input channels over blockIdx.z, fp32 slabs + a
     // fixed-order reduce.  Against the split-K gather kernel (igemm_fat) the activations are staged ONCE per chunk with
@@ -1248,6 +1253,7 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   dim3 grid(g.NT, g.Co / BN);
   if (BN == 32 && TZ == 4 && TY == 4 && TX == 16 && dt != RX_F32 && g.Ci == 32 && g.Co == 32 && g.NT >= 512 && !getenv("RX_NO_CH32P")) {
     rx_note_kernel("conv_halo32p_kernel");               // 32 -> 32 channels: persistent, weights stationary in LDS
+    if (in->cs || out->cs) RX_FAIL(RX_EUNSUPPORTED, "conv_halo32p: planar-concat operand");
     const bool fuse32 = stat_part && stat_chunks && !flip && !accumulate && (size_t)g.N * 1024 * 2 * g.Co * sizeof(float) <= stat_bytes;
     g.stat_part = fuse32 ? stat_part : nullptr;
     if (dt == RX_BF16)
@@ -1266,6 +1272,7 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   ConvHaloGeom g1 = g;                                // one tile per workgroup: bricks of tiles where the tile grid allows
   if (g.order && g.tx_n % 4 == 0 && g.ty_n % 4 == 0 && g.tz_n % 4 == 0) g1.order = 2;
   if (BN == 32 && TZ == 4 && TY == 4 && TX == 16) {  // full-resolution layers: compile-time tile, padded rows
+    if (out->cs) RX_FAIL(RX_EUNSUPPORTED, "conv_halo32: planar-concat output");
     rx_note_kernel("conv_halo32_kernel");
     switch (dt) {
       case RX_F32: ch32_launch<float>(grid, st, in->ptr, w, bias, out->ptr, g1); break;
@@ -1287,6 +1294,7 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   }
   if (g.Co % 64 == 0 && TZ == 4 && TY == 4 && TX == 16 && dt != RX_F32 && ch64ws &&
       (ch64ws == 2 || (long)g.NT * (g.Co / 64) >= 256)) {
+    if (in->cs) RX_FAIL(RX_EUNSUPPORTED, "conv_halo64ws: planar-concat input");
     rx_note_kernel("conv_halo64ws_kernel");
     static int st64 = -1;    // RX_CH64_STATS=0: statistics of the 64-channel-block layers by the separate pass
     if (st64 < 0) {
@@ -1308,6 +1316,7 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
     g.stat_part = nullptr;
     return 1;
   }
+  if (in->cs || out->cs) RX_FAIL(RX_EUNSUPPORTED, "conv_halo: planar-concat operand on the generic halo kernel");
   rx_note_kernel(BN == 64 ? "conv_halo_kernel<64>" : "conv_halo_kernel<32>");
   switch (dt) {
     case RX_F32: ch_dispatch<float>(BN, grid, st, in->ptr, w, bias, out->ptr, g1); break;

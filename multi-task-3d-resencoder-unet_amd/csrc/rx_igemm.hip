@@ -515,7 +515,7 @@ static void geom_out(IgemmGeom& g, const rx_act* a) {
 
 extern "C" int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, const float* bias, const rx_act* y,
                              const int32_t kernel[3], const int32_t stride[3], void* ws, size_t wsb, void* stream) {
-  if (!rx_act_ok(x) || !rx_act_ok(y) || !w_fwd) RX_FAIL(RX_EINVAL, "rx_conv3d_fwd: bad arguments");
+  if (!rx_act_ok_planar(x) || !rx_act_ok(y) || !w_fwd) RX_FAIL(RX_EINVAL, "rx_conv3d_fwd: bad arguments");
   int rc = check13(kernel, stride, "rx_conv3d_fwd");
   if (rc) return rc;
   if (y->n != x->n || y->z != conv_out_dim(x->z, kernel[0], stride[0]) || y->y != conv_out_dim(x->y, kernel[1], stride[1]) ||
@@ -526,6 +526,7 @@ extern "C" int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, co
     if (rc < 0) return rc;
     if (rc == 1) return RX_OK;
   }
+  if (x->cs) RX_FAIL(RX_EUNSUPPORTED, "rx_conv3d_fwd: a planar-concat input needs the 3x3x3 stride-1 halo kernel (Co = 32, X >= 16)");
   IgemmGeom g;
   memset(&g, 0, sizeof(g));
   geom_in(g, x);
@@ -552,7 +553,7 @@ extern "C" int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, co
 extern "C" int rx_conv3d_fwd_stats(rx_dtype dt, const rx_act* x, const void* w_fwd, const float* bias, const rx_act* y,
                                    const int32_t kernel[3], const int32_t stride[3], float eps, float* stats, void* ws, size_t wsb,
                                    void* stream) {
-  if (!rx_act_ok(x) || !rx_act_ok(y) || !w_fwd || !stats || !ws) RX_FAIL(RX_EINVAL, "rx_conv3d_fwd_stats: bad arguments");
+  if (!rx_act_ok_planar(x) || !rx_act_ok(y) || !w_fwd || !stats || !ws) RX_FAIL(RX_EINVAL, "rx_conv3d_fwd_stats: bad arguments");
   int rc = check13(kernel, stride, "rx_conv3d_fwd_stats");
   if (rc) return rc;
   if (is_333_s1(kernel, stride) && y->n == x->n && y->z == x->z && y->y == x->y && y->x == x->x) {
@@ -579,7 +580,7 @@ extern "C" int rx_conv3d_fwd_stats(rx_dtype dt, const rx_act* x, const void* w_f
 
 extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx, const int32_t kernel[3],
                                   const int32_t stride[3], int accumulate, void* ws, size_t wsb, void* stream) {
-  if (!rx_act_ok(dy) || !rx_act_ok(dx) || !w_bwd) RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_data: bad arguments");
+  if (!rx_act_ok(dy) || !rx_act_ok_planar(dx) || !w_bwd) RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_data: bad arguments");
   int rc = check13(kernel, stride, "rx_conv3d_bwd_data");
   if (rc) return rc;
   if (dy->n != dx->n || dy->z != conv_out_dim(dx->z, kernel[0], stride[0]) || dy->y != conv_out_dim(dx->y, kernel[1], stride[1]) ||
@@ -590,6 +591,7 @@ extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_b
     if (rc < 0) return rc;
     if (rc == 1) return RX_OK;
   }
+  if (dx->cs) RX_FAIL(RX_EUNSUPPORTED, "rx_conv3d_bwd_data: a planar-concat dx needs the wave-specialised 64-channel halo kernel");
   if (kernel[0] == 3 && kernel[1] == 3 && kernel[2] == 3 && stride[0] == 2 && stride[1] == 2 && stride[2] == 2) {
     rc = rx_dgrad_s2_halo_try(dt, dy, w_bwd, dx, accumulate, (hipStream_t)stream);   // LDS-halo kernel, all 8 parity classes
     if (rc < 0) return rc;

@@ -315,7 +315,7 @@ int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, const int3
                       hipStream_t st);
 
 extern "C" size_t rx_conv3d_bwd_weight_workspace(const rx_act* x, const rx_act* dy, const int32_t kernel[3]) {
-  if (!rx_act_ok(x) || !rx_act_ok(dy)) return 0;
+  if (!rx_act_ok_planar(x) || !rx_act_ok(dy)) return 0;
   size_t a = wgrad_ws_bytes(dy->c, x->c, kernel[0] * kernel[1] * kernel[2], (long)dy->n * rx_act_voxels(dy));
   size_t b = (kernel[0] == 3 && kernel[1] == 3 && kernel[2] == 3) ? rx_wgrad_halo_ws_bytes(x, dy) : 0;
   return a > b ? a : b;
@@ -323,7 +323,7 @@ extern "C" size_t rx_conv3d_bwd_weight_workspace(const rx_act* x, const rx_act* 
 
 extern "C" int rx_conv3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw, const int32_t kernel[3],
                                     const int32_t stride[3], void* ws, size_t ws_bytes, void* stream) {
-  if (!rx_act_ok(x) || !rx_act_ok(dy)) RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_weight: bad arguments");
+  if (!rx_act_ok_planar(x) || !rx_act_ok(dy)) RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_weight: bad arguments");
   for (int i = 0; i < 3; ++i) {
     if (kernel[i] != 1 && kernel[i] != 3) RX_FAIL(RX_EUNSUPPORTED, "rx_conv3d_bwd_weight: kernel sizes must be 1 or 3");
     if (stride[i] != 1 && stride[i] != 2) RX_FAIL(RX_EUNSUPPORTED, "rx_conv3d_bwd_weight: strides must be 1 or 2");
@@ -336,6 +336,7 @@ extern "C" int rx_conv3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* 
     if (rc < 0) return rc;
     if (rc == 1) return RX_OK;
   }
+  if (x->cs) RX_FAIL(RX_EUNSUPPORTED, "rx_conv3d_bwd_weight: a planar-concat x needs the LDS-halo weight-gradient kernels");
   WgradGeom g;
   memset(&g, 0, sizeof(g));
   g.Qz = dy->z, g.Qy = dy->y, g.Qx = dy->x, g.Vq = (int)rx_act_voxels(dy), g.NQ = dy->n * g.Vq;

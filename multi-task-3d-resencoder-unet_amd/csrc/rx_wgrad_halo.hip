@@ -24,6 +24,7 @@ struct WgHaloGeom {
   int N, Z, Y, X;
   int R, Cc, ldg, ldx;
   long g_ss, x_ss;
+  long x_cs;             // planar concat x (rx_act.cs): element offset of 32-channel group j = j * x_cs; 0 = contiguous channels
   int TZ, TY, TX, lTX, lTY;
   int HY, HX, HV, VT;
   int tz_n, ty_n, tx_n, NT;
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const T* __restrict_
   const int split = lid / PPn, pp = lid - split * PPn;
   const int pr = pp / g.panels_c, pc = pp - pr * g.panels_c;
   const int r0 = pr * 32, c0 = pc * 32;
+  const long xc0 = g.x_cs ? (long)pc * g.x_cs : (long)c0;      // where this panel's 32 input channels start
   const int t_begin = split * g.tiles_per_split;
   const int t_end = min(g.NT, t_begin + g.tiles_per_split);
 
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const T* __restrict_
     rx_tile_coords(tile, g.tx_n, g.ty_n, g.tz_n, g.order, n, tz, ty, tx);
     const int z0 = tz * g.TZ, y0 = ty * g.TY, x0 = tx * g.TX;
     const T* gn = gt + n * g.g_ss + r0;
-    const T* xn = xt + n * g.x_ss + c0;
+    const T* xn = xt + n * g.x_ss + xc0;
 #pragma unroll
     for (int p = 0; p < RX_WGH_GPIECES; ++p) {
       int v = (tid >> 2) + 64 * p;
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_halo16_kernel(const T* __restric
   const int split = lid / PPn, pp = lid - split * PPn;
   const int pr = pp / g.panels_c, pc = pp - pr * g.panels_c;
   const int r0 = pr * 32, c0 = pc * 32;
+  const long xc0 = g.x_cs ? (long)pc * g.x_cs : (long)c0;      // where this panel's 32 input channels start
   const int t_begin = split * g.tiles_per_split;
   const int t_end = min(g.NT, t_begin + g.tiles_per_split);
 
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_halo16_kernel(const T* __restric
     rx_tile_coords(tile, g.tx_n, g.ty_n, g.tz_n, g.order, n, tz, ty, tx);
     s_z0 = tz * 4, s_y0 = ty * 4, s_x0 = tx * 16;
     s_gn = gt + n * g.g_ss + r0 + chunk * 8;
-    s_xn = xt + n * g.x_ss + c0 + chunk * 8;
+    s_xn = xt + n * g.x_ss + xc0 + chunk * 8;
   };
   auto issue_piece = [&](int p) {       // p in [0, 15); p is a compile-time constant at every call site
     if (p < 4) {
@@ -452,6 +455,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo16ws_kernel(const T* __restr
   const int split = lid / PPn, pp = lid - split * PPn;
   const int pr = pp / g.panels_c, pc = pp - pr * g.panels_c;
   const int r0 = pr * 32, c0 = pc * 32;
+  const long xc0 = g.x_cs ? (long)pc * g.x_cs : (long)c0;      // where this panel's 32 input channels start
   const int t_begin = split * g.tiles_per_split;
   const int t_end = min(g.NT, t_begin + g.tiles_per_split);
 
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo16ws_kernel(const T* __restr
       rx_tile_coords(tile, g.tx_n, g.ty_n, g.tz_n, g.order, n, tz, ty, tx);
       const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
       const T* gn = gt + n * g.g_ss + r0 + chunk * 8;
-      const T* xn = xt + n * g.x_ss + c0 + chunk * 8;
+      const T* xn = xt + n * g.x_ss + xc0 + chunk * 8;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int v = (ptid >> 2) + 64 * p;
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo16ws_kernel(const T* __restr
     };
     if (DMA) {
       const unsigned OOB = 0x7fffff00u;
-      const long gbytes = (long)g.N * g.g_ss * 2, xbytes = (long)g.N * g.x_ss * 2;
+      const long gbytes = (long)g.N * g.g_ss * 2, xbytes = ((long)g.N * g.x_ss + (g.x_cs ? (long)(g.Cc / 32 - 1) * g.x_cs : 0)) * 2;
       __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)gt, 0, (unsigned)(gbytes > 0xfffffff0L ? 0xfffffff0L : gbytes), 0x00020000);
       __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)xt, 0, (unsigned)(xbytes > 0xfffffff0L ? 0xfffffff0L : xbytes), 0x00020000);
       const int pw = wave - 4;
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo16ws_kernel(const T* __restr
         rx_tile_coords(tile, g.tx_n, g.ty_n, g.tz_n, g.order, n, tz, ty, tx);
         const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
         const unsigned gbase = (unsigned)((n * g.g_ss + r0 + chunk * 8) * 2);
-        const unsigned xbase = (unsigned)((n * g.x_ss + c0 + chunk * 8) * 2);
+        const unsigned xbase = (unsigned)((n * g.x_ss + xc0 + chunk * 8) * 2);
         __attribute__((address_space(3))) unsigned char* lG =
             (__attribute__((address_space(3))) unsigned char*)(smem + buf * WGH16_BUF_BYTES) + 1024 * pw;
         __attribute__((address_space(3))) unsigned char* lX = lG + 256 * 64;
@@ -649,6 +653,7 @@ static int wgh_plan(const rx_act* x, const rx_act* dy, const int32_t stride[3], 
   g->R = dy->c, g->Cc = x->c, g->ldg = dy->ld, g->ldx = x->ld;
   g->g_ss = rx_act_voxels(dy) * (long)dy->ld;
   g->x_ss = rx_act_voxels(x) * (long)x->ld;
+  g->x_cs = x->cs;
   const bool strided = stride[0] > 1 || stride[1] > 1 || stride[2] > 1;
   int TX = p2ceil(g->X);
   TX = TX < 4 ? 4 : (TX > 16 ? 16 : TX);
@@ -736,7 +741,8 @@ int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, const int3
       attr16 = true;
     }
     rx_note_kernel(ws_mode ? "wgrad_halo16ws_kernel" : "wgrad_halo16_kernel");
-    const bool dma_ok = dma_mode && (long)g.N * g.g_ss * 2 < 0x7fffff00L && (long)g.N * g.x_ss * 2 < 0x7fffff00L;
+    const bool dma_ok = dma_mode && (long)g.N * g.g_ss * 2 < 0x7fffff00L &&
+                        ((long)g.N * g.x_ss + (g.x_cs ? (long)(g.Cc / 32 - 1) * g.x_cs : 0)) * 2 < 0x7fffff00L;
     if (ws_mode && dma_ok && dt == RX_BF16)
       hipLaunchKernelGGL((wgrad_halo16ws_kernel<bf16_t, true>), grid, dim3(512), 2 * lds16, st, (const bf16_t*)dy->ptr, (const bf16_t*)x->ptr, (float*)ws, dw, g);
     else if (ws_mode && dma_ok)

@@ -22,7 +22,7 @@ class RxError(RuntimeError):
 class RxAct(ctypes.Structure):
     """mirror of `rx_act` (include/rxunet.h)"""
     _fields_ = [("ptr", c_void_p), ("n", c_int32), ("z", c_int32), ("y", c_int32), ("x", c_int32),
-                ("c", c_int32), ("ld", c_int32)]
+                ("c", c_int32), ("ld", c_int32), ("cs", ctypes.c_int64)]
 
 
 class RxSeParams(ctypes.Structure):

@@ -70,13 +70,40 @@ def workspace(nbytes=None, device=None):
 
 
 class Act:
-    __slots__ = ("t", "c0", "c")
+    __slots__ = ("t", "c0", "c", "root", "plane")
 
     def __init__(self, t, c0=0, c=None):
         assert t.dim() == 5 and t.is_contiguous(), "Act wraps a contiguous (n,z,y,x,ld) tensor"
         self.t, self.c0 = t, c0
         self.c = t.shape[4] - c0 if c is None else c
         assert 0 < self.c and c0 + self.c <= t.shape[4]
+        self.root, self.plane = None, None      # set for planar concats and their planes (see `planar`)
+
+    @staticmethod
+    def planar(root, plane=None):
+        """`root`: (G, n, z, y, x, 32) contiguous -- a concat of G 32-channel groups kept as G DENSE tensors (rx_act.cs).
+        plane=None: the whole concat (c = 32*G; only the 3x3x3 stride-1 conv entry points take it);
+        plane=j: group j, an ordinary dense activation that remembers where it lives."""
+        assert root.dim() == 6 and root.is_contiguous() and root.shape[5] == 32
+        a = Act(root[0 if plane is None else plane])
+        a.root, a.plane = root, plane
+        if plane is None:
+            a.c = 32 * root.shape[0]
+        return a
+
+    @property
+    def key(self):
+        """identity of the underlying buffer (gradient buffers are allocated per buffer, not per view)"""
+        return id(self.root) if self.root is not None else id(self.t)
+
+    @property
+    def is_planar_cat(self):
+        return self.root is not None and self.plane is None
+
+    @property
+    def full_buffer(self):
+        """does this view address every channel of its buffer?"""
+        return self.is_planar_cat or (self.root is None and self.c0 == 0 and self.c == self.t.shape[4])
 
     @staticmethod
     def empty(n, z, y, x, c, dtype, device="cuda"):
@@ -87,7 +114,12 @@ class Act:
         return Act(torch.zeros((n, z, y, x, c), dtype=dtype, device=device))
 
     def slice(self, c0, c):
-        return Act(self.t, self.c0 + c0, c)
+        if self.is_planar_cat:
+            assert c == 32 and c0 % 32 == 0, "a planar concat is sliced plane by plane"
+            return Act.planar(self.root, c0 // 32)
+        a = Act(self.t, self.c0 + c0, c)
+        a.root, a.plane = self.root, self.plane
+        return a
 
     @property
     def dtype(self):
@@ -104,10 +136,20 @@ class Act:
 
     def desc(self):
         s = self.t.shape
-        return RxAct(self.t.data_ptr() + self.c0 * self.t.element_size(), s[0], s[1], s[2], s[3], self.c, s[4])
+        if self.is_planar_cat:
+            return RxAct(self.root.data_ptr(), s[0], s[1], s[2], s[3], self.c, 32, self.root.stride(0))
+        return RxAct(self.t.data_ptr() + self.c0 * self.t.element_size(), s[0], s[1], s[2], s[3], self.c, s[4], 0)
+
+    def like(self, root_or_t):
+        """the same view (channel range / plane) of another buffer of the same shape (gradient buffers)"""
+        if self.root is not None:
+            return Act.planar(root_or_t, self.plane)
+        return Act(root_or_t, self.c0, self.c)
 
     def tensor(self):
         """(n, z, y, x, c) view of the addressed channels (for tests / debugging)."""
+        if self.is_planar_cat:
+            return torch.cat(list(self.root), dim=-1)
         return self.t[..., self.c0:self.c0 + self.c]
 
     def to_ncdhw(self):

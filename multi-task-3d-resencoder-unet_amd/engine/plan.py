@@ -155,6 +155,22 @@ class Plan:
         self.bytes_alloc += t.numel() * t.element_size()
         return AT(Act(t, 0, c), name, needs_grad=needs_grad)
 
+    def _new_cat(self, dims, c, name):
+        """concat buffer (upsampled | skip) of a decoder stage.  Interleaved (2c channels per voxel, the halves are channel
+        slices) in general; PLANAR -- two dense c-channel tensors, rx_act.cs -- for the 32-channel full-resolution level, where
+        a 64-byte slice of a 128-byte voxel costs every kernel that streams a half 1.5-2x (scripts/probes/strided_probe.py)
+        and the three conv kernels that read / write the whole concat can address its planes separately."""
+        vox = dims[0] * dims[1] * dims[2]
+        min_vox = int(os.environ.get("RX_PLANAR_MIN_VOXELS", str(64 ** 3)))
+        planar = (c == 32 and self.dtype != torch.float32 and not self.two_d and dims[2] % 16 == 0 and vox >= min_vox
+                  and self.B * (dims[0] // 4) * (dims[1] // 4) * (dims[2] // 16) >= 256
+                  and os.environ.get("RX_PLANAR_CAT", "1") != "0")
+        if not planar:
+            return self._new(dims, 2 * c, name, ld=2 * c)
+        root = torch.empty((2, self.B, *dims, 32), dtype=self.dtype, device=self.device)
+        self.bytes_alloc += root.numel() * root.element_size()
+        return AT(Act.planar(root), name)
+
     def _param(self, p):
         if id(p) not in self._pidx:
             self._pidx[id(p)] = len(self.params)
@@ -322,7 +338,7 @@ class Plan:
             row = []
             for j in range(n_st - 1):
                 es = n_st - 2 - j
-                row.append(self._new(dims[es], 2 * feats[es], f"cat{d}.{j}", ld=2 * feats[es]))
+                row.append(self._new_cat(dims[es], feats[es], f"cat{d}.{j}"))
             cats.append(row)
 
         def skip_home(es):
@@ -507,10 +523,10 @@ class Plan:
         cat_written = {}
 
         def mark_cat(cat):
-            cat_written[id(cat.act.t)] = True
+            cat_written[cat.act.key] = True
 
         def view_written(at):
-            return at.written or cat_written.get(id(at.act.t), False)
+            return at.written or cat_written.get(at.act.key, False)
 
         def new_grad(idx):
             # a FRESH tensor every backward (autograd may keep / accumulate into what we return); a gradient
@@ -642,7 +658,7 @@ class Plan:
                         gx = self._grad_buf(x)
                         acc = view_written(x)
                         x.written = True
-                        if x.act.c == x.act.t.shape[4] and x.act.c0 == 0:
+                        if x.act.full_buffer:
                             mark_cat(x)     # a full-buffer write initialises every channel view of it
                         b.append(lambda a=a, dy=dy, gx=gx, acc=acc: ops.conv3d_bwd_data(
                             dy, a["pk"]["w_bwd"], gx, a["kernel"], a["stride"], acc))
@@ -650,7 +666,7 @@ class Plan:
                     x, y = a["x"], a["y"]
                     if not view_written(y):
                         raise RuntimeError("plan bug: concat gradient not initialised before the transposed conv")
-                    gy = Act(a["cat"].gact.t, y.act.c0, y.act.c)
+                    gy = y.act.like(a["cat"].gact.root if a["cat"].gact.root is not None else a["cat"].gact.t)
                     gx = self._grad_buf(x)
                     acc = view_written(x)
                     x.written = True
@@ -678,7 +694,7 @@ class Plan:
                     b.append(lambda a=a, gy=y.gact, gx=gx, acc=acc: ops.avgpool_bwd(gy, gx, a["stride"], acc))
                 elif rec.kind == "copy":
                     x, y = a["x"], a["y"]
-                    gy = Act(a["cat"].gact.t, y.act.c0, y.act.c)
+                    gy = y.act.like(a["cat"].gact.root if a["cat"].gact.root is not None else a["cat"].gact.t)
                     gx = self._grad_buf(x)
                     acc = view_written(x)
                     x.written = True
@@ -688,12 +704,12 @@ class Plan:
         """gradient buffer of an activation; channel views of one buffer share one gradient buffer"""
         if at.gact is not None:
             return at.gact
-        base = at.act.t
-        if id(base) not in self._gbase:
+        base = at.act.root if at.act.root is not None else at.act.t
+        if at.act.key not in self._gbase:
             t = torch.empty_like(base)
             self.bytes_alloc += t.numel() * t.element_size()
-            self._gbase[id(base)] = t
-        at.gact = Act(self._gbase[id(base)], at.act.c0, at.act.c)
+            self._gbase[at.act.key] = t
+        at.gact = at.act.like(self._gbase[at.act.key])
         return at.gact
 
     # ------------------------------------------------------------------ run

@@ -307,3 +307,30 @@ def test_fp32_training_trajectory_matches_oracle(NetworkFromConfig):
     assert l_ref[-1] < l_ref[0] - 1e-3, "the oracle itself did not descend"
     for a, b in zip(l_ref, l_net):
         assert abs(a - b) < 2e-3 * max(1.0, abs(a)), (l_ref, l_net)
+
+
+def test_planar_concat_plan_matches_interleaved_plan(monkeypatch):
+    """RX_PLANAR_MIN_VOXELS lowered so that a 32^3 net takes the planar full-resolution concat: logits and every gradient must
+    equal the interleaved plan's (same kernels, same arithmetic, only the addressing of the concat halves differs)."""
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
+    tasks = {"sheet": {"channels": 1, "activation": "none", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
+    mgr = oracle.make_mgr((32, 32, 64), tasks, 1, 2, True, {})
+    x, t = oracle.synthetic_batch(2, 1, (32, 32, 64), tasks, 5)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RX_PLANAR_CAT", mode)
+        monkeypatch.setenv("RX_PLANAR_MIN_VOXELS", "1")
+        torch.manual_seed(7)
+        net = NetworkFromConfig(mgr).cuda()
+        net.compute_dtype = torch.bfloat16
+        out = net(x.cuda())
+        loss = oracle.train_loss(out, {k: v.cuda() for k, v in t.items()}, tasks)
+        loss.backward()
+        plan = next(iter(net._plans.values()))
+        cats = [r.a["cat"].act for r in plan.dec_tapes[0] if r.kind == "convT"]
+        assert any(c.is_planar_cat for c in cats) == (mode == "1")
+        res[mode] = (out["sheet"].detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+    assert torch.equal(res["0"][0], res["1"][0])
+    for n in res["0"][1]:
+        assert torch.equal(res["0"][1][n], res["1"][1][n]), n

@@ -330,3 +330,46 @@ def test_instnorm_act_pool_fwd_is_the_two_calls(ops, dtype, stride):
     ops.instnorm_act_pool_fwd(y, stats, o2, p2, stride, 0.01, res)
     torch.cuda.synchronize()
     assert torch.equal(o1.t, o2.t) and torch.equal(p1.t, p2.t)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_planar_concat_convs_equal_interleaved(ops, dtype):
+    """rx_act.cs: the 64-channel concat as two dense 32-channel planes.  Forward (planar x), backward-data (planar dx, with and
+    without accumulation) and backward-weight (planar x) must reproduce the interleaved layout bit for bit."""
+    n, dims = 2, (16, 32, 64)                    # 4*8*4*2 = 256 tiles: the full-resolution kernels
+    xin = rnd((n, 64, *dims), dtype, 1)
+    inter = to_act(ops, xin, dtype)                                        # (n, z, y, x, 64)
+    root = torch.stack([inter.t[..., :32].contiguous(), inter.t[..., 32:].contiguous()], 0)
+    planar = ops.Act.planar(root)
+    assert planar.c == 64 and torch.equal(planar.tensor(), inter.t) and planar.slice(32, 32).plane == 1
+    w = rnd((32, 64, 3, 3, 3), torch.float32, 2, scale=0.05).float().cuda()
+    wf, wb = ops.pack_conv_weight(w, dtype)
+    k, s = (3, 3, 3), (1, 1, 1)
+    y1, y2 = ops.Act.empty(n, *dims, 32, dtype), ops.Act.empty(n, *dims, 32, dtype)
+    ops.conv3d_fwd(inter, wf, None, y1, k, s)
+    ops.conv3d_fwd(planar, wf, None, y2, k, s)
+    st1, st2 = torch.empty((n, 32, 2), device="cuda"), torch.empty((n, 32, 2), device="cuda")
+    ops.conv3d_fwd_stats(planar, wf, None, y2, k, s, st2)
+    ops.instnorm_stats(y1, st1)
+    torch.cuda.synchronize()
+    assert torch.equal(y1.t, y2.t) and torch.allclose(st1, st2, rtol=2e-5, atol=2e-6)
+    gy = to_act(ops, rnd((n, 32, *dims), dtype, 3, scale=0.1), dtype)
+    base = rnd((n, 64, *dims), dtype, 4, scale=0.1)
+    for acc in (False, True):
+        d1 = to_act(ops, base, dtype)
+        d2 = ops.Act.planar(torch.stack([d1.t[..., :32].contiguous(), d1.t[..., 32:].contiguous()], 0))
+        ops.conv3d_bwd_data(gy, wb, d1, k, s, acc)
+        ops.conv3d_bwd_data(gy, wb, d2, k, s, acc)
+        torch.cuda.synchronize()
+        assert torch.equal(d1.t, d2.tensor()), acc
+    dw1, dw2 = torch.empty_like(w), torch.empty_like(w)
+    ops.conv3d_bwd_weight(inter, gy, dw1, k, s)
+    ops.conv3d_bwd_weight(planar, gy, dw2, k, s)
+    torch.cuda.synchronize()
+    assert torch.equal(dw1, dw2)
+    from mt3d_amd.engine.lib import RxError
+    small = ops.Act.planar(torch.zeros((2, 1, 4, 4, 16, 32), dtype=dtype, device="cuda"))     # too small for the halo kernels
+    with pytest.raises(RxError):
+        ops.conv3d_fwd(small, wf, None, ops.Act.empty(1, 4, 4, 16, 32, dtype), k, s)
+    with pytest.raises(RxError):
+        ops.instnorm_stats(planar, torch.empty((n, 64, 2), device="cuda"))              # every other entry point refuses cs != 0
