@@ -84,6 +84,16 @@ int rx_conv3d_fwd_stats(rx_dtype dt, const rx_act* x, const void* w_fwd, const f
 int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx,
                        const int32_t kernel[3], const int32_t stride[3], int accumulate, void* ws,
                        size_t ws_bytes, void* stream);
+/* backward-data that also delivers the two means of the InstanceNorm backward of the layer whose OUTPUT gradient it completes
+ * (dx = dL/d(out of that layer); in_y / in_stats / slope describe it; the layer has no residual: its LeakyReLU mask is the
+ * sign of the normalised value; the caller guarantees nothing adds to dx afterwards).  On the persistent 32-channel halo
+ * kernel  sum g'  and  sum g'*(y - mean)  are per-lane running sums of the epilogue (y prefetched under the MFMA loop):
+ * *fused = 1, m12[n][c] = (mean g', mean g'*xhat), continue with rx_instnorm_act_bwd_apply.  Otherwise *fused = 0 and m12 is
+ * untouched: continue with rx_instnorm_act_bwd. */
+int rx_conv3d_bwd_data_instats(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx,
+                               const int32_t kernel[3], const int32_t stride[3], int accumulate, const rx_act* in_y,
+                               const float* in_stats, float slope, float* m12, int* fused, void* ws, size_t ws_bytes,
+                               void* stream);
 /* dw (Co,Ci,T) fp32 = sum over voxels; workspace from rx_conv3d_bwd_weight_workspace() */
 size_t rx_conv3d_bwd_weight_workspace(const rx_act* x, const rx_act* dy, const int32_t kernel[3]);
 int rx_conv3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw, const int32_t kernel[3],
@@ -117,6 +127,11 @@ int rx_instnorm_fwd(rx_dtype dt, const rx_act* y, float eps, float* stats, const
 int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out,
                         float slope, const rx_act* dy, const rx_act* d_residual, int accumulate_residual,
                         void* ws, size_t ws_bytes, void* stream);
+
+/* second pass of rx_instnorm_act_bwd alone, with the two means m12[n][c] supplied by the caller */
+int rx_instnorm_act_bwd_apply(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out,
+                              float slope, const float* m12, const rx_act* dy, const rx_act* d_residual,
+                              int accumulate_residual, void* stream);
 
 /* ---- SqueezeExcite + DropPath of the residual blocks (resblocks.py:79-87,109-112 BasicBlockD; :203-212,234-240
  *      BottleneckD).  Both classes come from the un-vendored dynamic_network_architectures package: PARITY UNPINNED

@@ -35,6 +35,13 @@ void rx_note_kernel(const char* name);   // records which kernel instantiation t
     if (e__ != hipSuccess) RX_FAIL(RX_ELAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
   } while (0)
 
+// what a backward-data launch needs to know about the InstanceNorm layer (without residual) whose output gradient it completes
+struct RxBwdStat {
+  const rx_act* y;      // saved conv output of that layer
+  const float* stats;   // its (mean, rstd)
+  float slope;
+};
+
 // Ablation switches of the halo kernels (RX_DBG env -> geometry.dbg): compiled in only with -DRX_ABLATION=1.  Run-time flags
 // are not free in these kernels (DESIGN §8 row y), so the production build folds them away.
 #ifndef RX_ABLATION

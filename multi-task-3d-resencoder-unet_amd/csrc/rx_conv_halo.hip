@@ -27,6 +27,14 @@ struct ConvHaloGeom {
   int order;                  // tile walk order (rx_tile_coords)
   int wgs_s;                  // persistent kernels: workgroups per SAMPLE (tile ranges never straddle samples); 0 = off
   float* stat_part;           // fused InstanceNorm statistics: per-wave partial sums, or nullptr (see ch_stat_flush)
+  // conv_halo32p<.., BS>: backward-data launches that COMPLETE the gradient of an InstanceNorm layer's output also accumulate
+  // that layer's two backward sums  s1 = sum g',  s2 = sum g'*(y - mean)  (g' = g * lrelu'(xhat): layers without a residual,
+  // whose mask is the sign of y - mean) the same way -- y prefetched under the MFMA loop.  bs_y / bs_stats describe the layer.
+  const void* bs_y;
+  const float* bs_stats;
+  int bs_ldy;
+  long bs_yss;
+  float bs_slope;
   int accumulate, flip, dbg;  // dbg: ablation mask (RX_DBG env): 1 no halo loads, 2 no weight loads, 4 no MFMA, 8 no stores
 };
 
@@ -460,7 +468,7 @@ __device__ inline void ch_stat_flush(float (&s1)[NA][16], float (&s2)[NA][16], f
 // STATS: forward instantiation that accumulates the InstanceNorm statistics of its output; ACC: dx += (old values prefetched
 // under the MFMA loop).  Compile-time so that the plain variant keeps its 103 registers: with run-time flags the statistics
 // code alone cost every launch 10-17 % (306 -> 358 us for the 32 -> 32 data gradient @128^3).
-template <typename T, bool STATS = false, bool ACC = false, bool FLIP = false>
+template <typename T, bool STATS = false, bool ACC = false, bool FLIP = false, bool BS = false>
 __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
                                                               T* __restrict__ out, const ConvHaloGeom g, int tiles_per_wg) {
   constexpr int P = Elem<T>::PER16;
@@ -558,14 +566,19 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
     float s1[1][16], s2[1][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) s1[0][r] = 0.f, s2[0][r] = 0.f;
+    float bmean[16];
+    if (BS) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bmean[r] = g.bs_stats[2 * ((size_t)sn * g.Co + 8 * (r >> 2) + 4 * fh + (r & 3))];
+    }
     __syncthreads();                                    // weights + tile 0
     for (int tile = t_begin; tile < t_end; ++tile) {
       const int buf = (tile - t_begin) & 1;
       const unsigned char* sX = sX0 + buf * CH32P_HALO_BYTES;
       // accumulate (dx += ...): the old values are fetched HERE, under the MFMA loop -- read in the epilogue they cost a full
       // memory round trip per tile (32->32 dgrad @128^3: 306 us without, 540 us with accumulation)
-      u32x2 oldv[2][4];
-      if (ACC) {
+      u32x2 oldv[2][4], yq[2][4];
+      if (ACC || BS) {
         int n_, z0_, y0_, x0_;
         tile_origin(tile, n_, z0_, y0_, x0_);
 #pragma unroll
@@ -573,9 +586,17 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
           const int v = (wave * 2 + b) * 32 + fv;
           const int z = z0_ + (v >> 6), y = y0_ + ((v >> 4) & 3), x = x0_ + (v & 15);
           const bool ok = z < g.Z && y < g.Y && x < g.X;
-          const T* op = out + (long)n_ * g.out_ss + ((long)(z * g.Y + y) * g.X + x) * g.ldo + 4 * fh;
+          const long vox = (long)(z * g.Y + y) * g.X + x;
+          if (ACC) {
+            const T* op = out + (long)n_ * g.out_ss + vox * g.ldo + 4 * fh;
 #pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) oldv[b][g4] = ok ? *reinterpret_cast<const u32x2*>(op + 8 * g4) : u32x2{0u, 0u};
+            for (int g4 = 0; g4 < 4; ++g4) oldv[b][g4] = ok ? *reinterpret_cast<const u32x2*>(op + 8 * g4) : u32x2{0u, 0u};
+          }
+          if (BS) {
+            const T* yp = (const T*)g.bs_y + (long)n_ * g.bs_yss + vox * g.bs_ldy + 4 * fh;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) yq[b][g4] = ok ? *reinterpret_cast<const u32x2*>(yp + 8 * g4) : u32x2{0u, 0u};
+          }
         }
       }
       f32x16 acc[2];
@@ -638,13 +659,20 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
               s1[0][4 * g4 + i] += r;
               s2[0][4 * g4 + i] += r * r;
             }
+            if (BS) {
+              float gg = Elem<T>::to_f(vals[i]);       // the gradient as stored
+              const float yc = Elem<T>::to_f(reinterpret_cast<const T*>(&yq[b][g4])[i]) - bmean[4 * g4 + i];
+              if (!(yc > 0.f)) gg *= g.bs_slope;       // (slope == 1: no activation, nothing changes)
+              s1[0][4 * g4 + i] += gg;
+              s2[0][4 * g4 + i] += gg * yc;
+            }
           }
           *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
         }
       }
       lds_only_barrier();      // the stores of this tile stay in flight under the next tile's MFMAs
     }
-    if (STATS) ch_stat_flush<1>(s1, s2, g.stat_part, sn, g.wgs_s * 4, sl * 4 + wave, g.Co, 0, lane);
+    if (STATS || BS) ch_stat_flush<1>(s1, s2, g.stat_part, sn, g.wgs_s * 4, sl * 4 + wave, g.Co, 0, lane);
   }
 }
 
@@ -1071,6 +1099,8 @@ static void ch32p_launch(hipStream_t st, const void* in, const void* w, const fl
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32p_kernel<T, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32p_kernel<T, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32p_kernel<T, false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32p_kernel<T, false, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32p_kernel<T, false, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
   int wgs = g.NT < 256 ? g.NT : 256;                    // one persistent workgroup per CU
@@ -1081,6 +1111,11 @@ static void ch32p_launch(hipStream_t st, const void* in, const void* w, const fl
   wgs = wgs_s * g.N;
   const_cast<ConvHaloGeom&>(g).wgs_s = wgs_s;
 #define RX_32P(S, A, F) hipLaunchKernelGGL((conv_halo32p_kernel<T, S, A, F>), dim3(wgs), dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per)
+#define RX_32PB(A) hipLaunchKernelGGL((conv_halo32p_kernel<T, false, A, true, true>), dim3(wgs), dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per)
+  if (g.bs_y && g.flip && g.accumulate) RX_32PB(true);
+  else if (g.bs_y && g.flip) RX_32PB(false);
+  else
+#undef RX_32PB
   if (g.stat_part && !g.accumulate && !g.flip) RX_32P(true, false, false);
   else if (g.flip && g.accumulate) RX_32P(false, true, true);
   else if (g.flip) RX_32P(false, false, true);
@@ -1142,7 +1177,8 @@ static void ch_dispatch(int BN, dim3 grid, hipStream_t st, const void* in, const
 // stat_part / stat_chunks (forward only, optional): when the launch goes to a persistent kernel, per-wave partial sums of
 // y and y^2 are left in stat_part ([n][*stat_chunks][2][Co] floats) and *stat_chunks > 0; otherwise *stat_chunks = 0.
 int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* bias, const rx_act* out, int flip, int accumulate,
-                     void* ws, size_t ws_bytes, hipStream_t st, float* stat_part, size_t stat_bytes, int* stat_chunks) {
+                     void* ws, size_t ws_bytes, hipStream_t st, float* stat_part, size_t stat_bytes, int* stat_chunks,
+                     const RxBwdStat* bs) {
   if (stat_chunks) *stat_chunks = 0;
   const int per16 = dt == RX_F32 ? 4 : 8;
   const int KB = 4 * per16;
@@ -1254,8 +1290,13 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   if (BN == 32 && TZ == 4 && TY == 4 && TX == 16 && dt != RX_F32 && g.Ci == 32 && g.Co == 32 && g.NT >= 512 && !getenv("RX_NO_CH32P")) {
     rx_note_kernel("conv_halo32p_kernel");               // 32 -> 32 channels: persistent, weights stationary in LDS
     if (in->cs || out->cs) RX_FAIL(RX_EUNSUPPORTED, "conv_halo32p: planar-concat operand");
-    const bool fuse32 = stat_part && stat_chunks && !flip && !accumulate && (size_t)g.N * 1024 * 2 * g.Co * sizeof(float) <= stat_bytes;
+    const bool room = stat_part && stat_chunks && (size_t)g.N * 1024 * 2 * g.Co * sizeof(float) <= stat_bytes;
+    const bool fuse32 = room && ((!flip && !accumulate && !bs) || (flip && bs));
     g.stat_part = fuse32 ? stat_part : nullptr;
+    if (fuse32 && bs) {
+      g.bs_y = bs->y->ptr, g.bs_ldy = bs->y->ld, g.bs_yss = rx_act_voxels(bs->y) * (long)bs->y->ld;
+      g.bs_stats = bs->stats, g.bs_slope = bs->slope;
+    }
     if (dt == RX_BF16)
       ch32p_launch<bf16_t>(st, in->ptr, w, bias, out->ptr, g);
     else
@@ -1266,7 +1307,7 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
       return RX_ELAUNCH;
     }
     if (fuse32) *stat_chunks = g.wgs_s * 4;
-    g.stat_part = nullptr;
+    g.stat_part = nullptr, g.bs_y = nullptr;
     return 1;
   }
   ConvHaloGeom g1 = g;                                // one tile per workgroup: bricks of tiles where the tile grid allows

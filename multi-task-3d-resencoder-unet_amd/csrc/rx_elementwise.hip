@@ -703,6 +703,68 @@ extern "C" int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y
 }
 
 
+// ---- InstanceNorm backward with the two means supplied by the caller ------------------------------------------------
+// (rx_conv3d_bwd_data_instats: the persistent backward-data kernel accumulates sum g' and sum g'*(y - mean) in its epilogue)
+__global__ __launch_bounds__(256) void inbwd_fused_finalize(const float* __restrict__ partial, int N, int nchunks, int C, double V,
+                                                            const float* __restrict__ stats, float* __restrict__ m12) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C;
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = lane; k < nchunks; k += 64) {
+    const float* p = partial + ((size_t)(n * nchunks + k) * 2) * C + c;
+    s0 += (double)p[0];
+    s1 += (double)p[C];
+  }
+  s0 = wave_sum_d(s0);
+  s1 = wave_sum_d(s1);
+  if (lane != 0) return;
+  m12[2 * i] = (float)(s0 / V);
+  m12[2 * i + 1] = (float)((double)stats[2 * i + 1] * s1 / V);     // sum g'*xhat = rstd * sum g'*(y - mean)
+}
+void rx_inbwd_fused_finalize_launch(const float* partial, int N, int nchunks, int C, double V, const float* stats, float* m12, hipStream_t st) {
+  hipLaunchKernelGGL(inbwd_fused_finalize, dim3((N * C + 3) / 4), dim3(256), 0, st, partial, N, nchunks, C, V, stats, m12);
+}
+
+extern "C" int rx_instnorm_act_bwd_apply(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out, float slope,
+                                         const float* m12, const rx_act* dy, const rx_act* d_residual, int accumulate_residual,
+                                         void* stream) {
+  int rc;
+  if ((rc = check_vec_channels(g, dt, "rx_instnorm_act_bwd_apply(g)"))) return rc;
+  if ((rc = check_vec_channels(y, dt, "rx_instnorm_act_bwd_apply(y)"))) return rc;
+  if ((rc = check_vec_channels(dy, dt, "rx_instnorm_act_bwd_apply(dy)"))) return rc;
+  const bool mask_xhat = slope != 1.0f && out == nullptr;
+  const bool use_mask = slope != 1.0f && out != nullptr;
+  if (use_mask) {
+    if ((rc = check_vec_channels(out, dt, "rx_instnorm_act_bwd_apply(out)"))) return rc;
+    if (!same_geom(y, out)) RX_FAIL(RX_EINVAL, "rx_instnorm_act_bwd_apply: out geometry mismatch");
+  }
+  if (d_residual) {
+    if ((rc = check_vec_channels(d_residual, dt, "rx_instnorm_act_bwd_apply(d_residual)"))) return rc;
+    if (!same_geom(y, d_residual)) RX_FAIL(RX_EINVAL, "rx_instnorm_act_bwd_apply: d_residual geometry mismatch");
+  }
+  if (!stats || !m12 || !same_geom(y, g) || !same_geom(y, dy)) RX_FAIL(RX_EINVAL, "rx_instnorm_act_bwd_apply: bad arguments");
+  const long V = rx_act_voxels(y);
+  const int N = y->n, C = y->c;
+  hipStream_t st = (hipStream_t)stream;
+  RX_DISPATCH_DTYPE(dt, T, {
+    constexpr int P = Elem<T>::PER16;
+    int CV = C / P;
+    int G = sweep_grid(V * CV, CV);
+    const T* outp = use_mask ? (const T*)out->ptr : nullptr;
+    int ldo = use_mask ? out->ld : 0;
+    if (!d_residual)
+      RX_LAUNCH_APPLY(false, false);
+    else if (accumulate_residual)
+      RX_LAUNCH_APPLY(true, true);
+    else
+      RX_LAUNCH_APPLY(true, false);
+  });
+  RX_CHECK_LAUNCH("rx_instnorm_act_bwd_apply");
+  return RX_OK;
+}
+
 extern "C" int rx_instnorm_fwd(rx_dtype dt, const rx_act* y, float eps, float* stats, const rx_act* residual, const rx_act* out,
                                float slope, void* ws, size_t ws_bytes, void* stream) {
   int rc;

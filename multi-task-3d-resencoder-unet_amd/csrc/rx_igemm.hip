@@ -486,7 +486,9 @@ static int igemm_launch(rx_dtype dt, const void* in, const void* w, const float*
 
 // rx_conv_halo.hip
 int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* bias, const rx_act* out, int flip, int accumulate,
-                     void* ws, size_t ws_bytes, hipStream_t st, float* stat_part, size_t stat_bytes, int* stat_chunks);
+                     void* ws, size_t ws_bytes, hipStream_t st, float* stat_part, size_t stat_bytes, int* stat_chunks,
+                     const RxBwdStat* bs);
+void rx_inbwd_fused_finalize_launch(const float* partial, int N, int nchunks, int C, double V, const float* stats, float* m12, hipStream_t st);
 // rx_dgrad_s2.hip
 int rx_dgrad_s2_halo_try(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx, int accumulate, hipStream_t st);
 // rx_elementwise.hip
@@ -522,7 +524,7 @@ extern "C" int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, co
       y->x != conv_out_dim(x->x, kernel[2], stride[2]))
     RX_FAIL(RX_EINVAL, "rx_conv3d_fwd: output geometry mismatch");
   if (is_333_s1(kernel, stride)) {
-    rc = rx_conv_halo_try(dt, x, w_fwd, bias, y, 0, 0, ws, wsb, (hipStream_t)stream, nullptr, 0, nullptr);  // LDS-halo kernel
+    rc = rx_conv_halo_try(dt, x, w_fwd, bias, y, 0, 0, ws, wsb, (hipStream_t)stream, nullptr, 0, nullptr, nullptr);  // LDS-halo kernel
     if (rc < 0) return rc;
     if (rc == 1) return RX_OK;
   }
@@ -548,6 +550,44 @@ extern "C" int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, co
   return igemm_launch(dt, x->ptr, w_fwd, bias, y->ptr, g, x->n, ws, wsb, (hipStream_t)stream);
 }
 
+// backward-data + the two sums of the InstanceNorm backward of the layer whose output gradient this launch COMPLETES (dx =
+// dL/d(out of that layer); the layer has no residual, its LeakyReLU mask is the sign of the normalised value).  *fused = 1 and
+// m12[n][c] = (mean g', mean g'*xhat) when the launch ran on the persistent 32-channel kernel (continue with
+// rx_instnorm_act_bwd_apply); otherwise *fused = 0, m12 untouched (continue with rx_instnorm_act_bwd).  The caller guarantees
+// that nothing adds to dx afterwards.
+extern "C" int rx_conv3d_bwd_data_instats(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx, const int32_t kernel[3],
+                                          const int32_t stride[3], int accumulate, const rx_act* in_y, const float* in_stats, float slope,
+                                          float* m12, int* fused, void* ws, size_t wsb, void* stream) {
+  if (!fused || !m12 || !in_stats || !rx_act_ok(in_y) || !ws) RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_data_instats: bad arguments");
+  *fused = 0;
+  if (!rx_act_ok(dy) || !rx_act_ok(dx) || !w_bwd) RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_data_instats: bad arguments");
+  int rc = check13(kernel, stride, "rx_conv3d_bwd_data_instats");
+  if (rc) return rc;
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("RX_FUSED_BWD_STATS");
+    on = e ? atoi(e) : 1;
+  }
+  const bool same = in_y->n == dx->n && in_y->z == dx->z && in_y->y == dx->y && in_y->x == dx->x && in_y->c == dx->c;
+  if (on && same && is_333_s1(kernel, stride) && dx->z == dy->z && dx->y == dy->y && dx->x == dy->x && in_y->ld % 4 == 0 &&
+      !((uintptr_t)in_y->ptr & 7)) {
+    RxBwdStat bs{in_y, in_stats, slope};
+    int chunks = 0;
+    rc = rx_conv_halo_try(dt, dy, w_bwd, nullptr, dx, 1, accumulate, nullptr, 0, (hipStream_t)stream, (float*)ws, wsb, &chunks, &bs);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+      if (chunks > 0) {
+        rx_inbwd_fused_finalize_launch((const float*)ws, dx->n, chunks, dx->c, (double)rx_act_voxels(dx), in_stats, m12, (hipStream_t)stream);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) RX_FAIL(RX_ELAUNCH, "rx_conv3d_bwd_data_instats(finalize): %s", hipGetErrorString(e));
+        *fused = 1;
+      }
+      return RX_OK;
+    }
+  }
+  return rx_conv3d_bwd_data(dt, dy, w_bwd, dx, kernel, stride, accumulate, ws, wsb, stream);
+}
+
 // conv + InstanceNorm statistics of its output in one call.  When the layer runs on a persistent halo kernel the sums of y and
 // y^2 come out of the conv epilogue (no extra pass over y); otherwise this is rx_conv3d_fwd followed by rx_instnorm_stats.
 extern "C" int rx_conv3d_fwd_stats(rx_dtype dt, const rx_act* x, const void* w_fwd, const float* bias, const rx_act* y,
@@ -563,7 +603,7 @@ extern "C" int rx_conv3d_fwd_stats(rx_dtype dt, const rx_act* x, const void* w_f
       fuse = e ? atoi(e) : 1;
     }
     int chunks = 0;
-    rc = rx_conv_halo_try(dt, x, w_fwd, bias, y, 0, 0, nullptr, 0, (hipStream_t)stream, fuse ? (float*)ws : nullptr, wsb, &chunks);
+    rc = rx_conv_halo_try(dt, x, w_fwd, bias, y, 0, 0, nullptr, 0, (hipStream_t)stream, fuse ? (float*)ws : nullptr, wsb, &chunks, nullptr);
     if (rc < 0) return rc;
     if (rc == 1 && chunks > 0) {
       rx_stats_finalize_launch((const float*)ws, y->n, chunks, y->c, (double)rx_act_voxels(y), eps, stats, (hipStream_t)stream);
@@ -587,7 +627,7 @@ extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_b
       dy->x != conv_out_dim(dx->x, kernel[2], stride[2]))
     RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_data: geometry mismatch");
   if (is_333_s1(kernel, stride)) {
-    rc = rx_conv_halo_try(dt, dy, w_bwd, nullptr, dx, 1, accumulate, ws, wsb, (hipStream_t)stream, nullptr, 0, nullptr);
+    rc = rx_conv_halo_try(dt, dy, w_bwd, nullptr, dx, 1, accumulate, ws, wsb, (hipStream_t)stream, nullptr, 0, nullptr, nullptr);
     if (rc < 0) return rc;
     if (rc == 1) return RX_OK;
   }

@@ -46,6 +46,9 @@ _SIGNATURES = {
     "rx_conv3d_fwd": (c_int, [c_int, _P, c_void_p, c_void_p, _P, I3, I3, c_void_p, c_size_t, c_void_p]),
     "rx_conv3d_fwd_stats": (c_int, [c_int, _P, c_void_p, c_void_p, _P, I3, I3, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rx_conv3d_bwd_data": (c_int, [c_int, _P, c_void_p, _P, I3, I3, c_int, c_void_p, c_size_t, c_void_p]),
+    "rx_conv3d_bwd_data_instats": (c_int, [c_int, _P, c_void_p, _P, I3, I3, c_int, _P, c_void_p, c_float, c_void_p, POINTER(c_int),
+                                           c_void_p, c_size_t, c_void_p]),
+    "rx_instnorm_act_bwd_apply": (c_int, [c_int, _P, _P, c_void_p, _P, c_float, c_void_p, _P, _P, c_int, c_void_p]),
     "rx_conv3d_bwd_weight_workspace": (c_size_t, [_P, _P, I3]),
     "rx_conv3d_bwd_weight": (c_int, [c_int, _P, _P, c_void_p, I3, I3, c_void_p, c_size_t, c_void_p]),
     "rx_convT3d_fwd": (c_int, [c_int, _P, c_void_p, c_void_p, _P, I3, c_void_p, c_size_t, c_void_p]),

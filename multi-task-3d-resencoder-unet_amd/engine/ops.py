@@ -243,6 +243,33 @@ def conv3d_bwd_data(dy, w_bwd, dx, kernel, stride, accumulate=False, ws=None):
     _PROF.run("dgrad:" + LaunchProfiler.igemm_name(dx.voxels, dx.c), 2.0 * n * dy.voxels * dy.c * dx.c * _taps(kernel), 1, go)
 
 
+def conv3d_bwd_data_instats(dy, w_bwd, dx, kernel, stride, accumulate, in_y, in_stats, slope, m12, ws=None):
+    """backward-data that completes dx = dL/d(out of an InstanceNorm layer without residual) and, on the persistent kernel,
+    leaves that layer's two backward means in m12.  Returns True when m12 was written (continue with instnorm_act_bwd_apply)."""
+    from ctypes import c_int
+    ws = workspace() if ws is None else ws
+    fused = c_int(0)
+
+    def go():
+        check(load().rx_conv3d_bwd_data_instats(_code(dy.dtype), byref(dy.desc()), _ptr(w_bwd), byref(dx.desc()), I3(*kernel),
+                                                I3(*stride), int(accumulate), byref(in_y.desc()), _ptr(in_stats), float(slope),
+                                                _ptr(m12), byref(fused), *_ws_args(ws), stream_ptr()), "rx_conv3d_bwd_data_instats")
+    if _PROF is None:
+        go()
+    else:
+        n = dx.dims[0]
+        _PROF.run("dgrad:" + LaunchProfiler.igemm_name(dx.voxels, dx.c), 2.0 * n * dx.voxels * dx.c * dy.c * _taps(kernel), 1, go)
+    return bool(fused.value)
+
+
+def instnorm_act_bwd_apply(g, y, stats, out, dy, m12, slope=0.01, d_residual=None, accumulate_residual=False):
+    check(load().rx_instnorm_act_bwd_apply(_code(y.dtype), byref(g.desc()), byref(y.desc()), _ptr(stats),
+                                           byref(out.desc()) if out is not None else None, float(slope), _ptr(m12),
+                                           byref(dy.desc()),
+                                           byref(d_residual.desc()) if d_residual is not None else None,
+                                           int(accumulate_residual), stream_ptr()), "rx_instnorm_act_bwd_apply")
+
+
 def conv3d_bwd_weight(x, dy, dw, kernel, stride, ws=None):
     need = load().rx_conv3d_bwd_weight_workspace(byref(x.desc()), byref(dy.desc()), I3(*kernel))
     ws = workspace(need) if ws is None else ws

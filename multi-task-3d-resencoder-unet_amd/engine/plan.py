@@ -567,6 +567,12 @@ class Plan:
 
         order = self.grad_order
 
+        # who wrote an activation's gradient LAST (plan-build order = run order): when the output gradient of an InstanceNorm
+        # layer WITHOUT residual is completed by a 3x3x3 backward-data launch, that launch can accumulate the layer's two
+        # backward sums in its epilogue (rx_conv3d_bwd_data_instats) and the reduce pass over (g, y) disappears
+        def wrote(at, kind, info=None):
+            at._gw = (kind, info)
+
         for tape in self.dec_tapes + [self.enc_tape]:
             for rec in reversed(tape):
                 a = rec.a
@@ -575,6 +581,7 @@ class Plan:
                     assert not view_written(x)
                     gx = self._grad_buf(x)
                     x.written = True
+                    wrote(x, "head")
 
                     def step(a=a, gx=gx):
                         dl = P._dlogits.get(a["name"])
@@ -603,6 +610,14 @@ class Plan:
                         gres = self._grad_buf(res)
                         acc = view_written(res)
                         res.written = True
+                        wrote(res, "gres")
+                    gw = getattr(out, "_gw", (None, None))
+                    if (gw[0] == "conv" and a["gate"] is None and res is None and self.dtype != torch.float32
+                            and out.act.full_buffer and out.act.root is None and out.act.c == 32 and out.act.voxels > 512
+                            and out.act.dims[3] >= 16 and os.environ.get("RX_FUSED_BWD_STATS", "1") != "0"):
+                        a["m12"] = torch.empty((self.B, out.act.c, 2), dtype=torch.float32, device=self.device)
+                        a["m12_valid"] = False
+                        gw[1]["inact"] = a          # that conv's backward-data step now also fills a["m12"]
                     def gistep(a=a, gout=gout, dy=dy, gres=gres, acc=acc):
                         g = a["gate"]
                         before_dy_write(dy)
@@ -629,9 +644,12 @@ class Plan:
                     def istep(a=a, gout=gout, dy=dy, gres=gres, acc=acc):
                         before_dy_write(dy)
                         # the saved output is only needed for the mask of residual blocks (sign(out) != sign(xhat) there)
-                        ops.instnorm_act_bwd(gout, a["y"].act, a["stats"],
-                                             a["out"].act if (a["slope"] != 1.0 and a["res"] is not None) else None, dy,
-                                             a["slope"], gres, acc)
+                        mask_out = a["out"].act if (a["slope"] != 1.0 and a["res"] is not None) else None
+                        if a.get("m12_valid"):      # the two means came out of the backward-data kernel that completed gout
+                            a["m12_valid"] = False
+                            ops.instnorm_act_bwd_apply(gout, a["y"].act, a["stats"], mask_out, dy, a["m12"], a["slope"], gres, acc)
+                        else:
+                            ops.instnorm_act_bwd(gout, a["y"].act, a["stats"], mask_out, dy, a["slope"], gres, acc)
                     b.append(istep)
                 elif rec.kind in ("conv", "stem"):
                     y = a["y"]
@@ -660,8 +678,17 @@ class Plan:
                         x.written = True
                         if x.act.full_buffer:
                             mark_cat(x)     # a full-buffer write initialises every channel view of it
-                        b.append(lambda a=a, dy=dy, gx=gx, acc=acc: ops.conv3d_bwd_data(
-                            dy, a["pk"]["w_bwd"], gx, a["kernel"], a["stride"], acc))
+                        bsinfo = {"inact": None}
+                        wrote(x, "conv", bsinfo)
+
+                        def dstep(a=a, dy=dy, gx=gx, acc=acc, bsinfo=bsinfo):
+                            ia = bsinfo["inact"]
+                            if ia is None:
+                                ops.conv3d_bwd_data(dy, a["pk"]["w_bwd"], gx, a["kernel"], a["stride"], acc)
+                            else:
+                                ia["m12_valid"] = ops.conv3d_bwd_data_instats(dy, a["pk"]["w_bwd"], gx, a["kernel"], a["stride"], acc,
+                                                                              ia["y"].act, ia["stats"], ia["slope"], ia["m12"])
+                        b.append(dstep)
                 elif rec.kind == "convT":
                     x, y = a["x"], a["y"]
                     if not view_written(y):
@@ -670,6 +697,7 @@ class Plan:
                     gx = self._grad_buf(x)
                     acc = view_written(x)
                     x.written = True
+                    wrote(x, "convT")
 
                     def step(a=a, gy=gy, gx=gx, acc=acc):
                         dw = new_grad(a["widx"])
@@ -690,6 +718,7 @@ class Plan:
                     gx = self._grad_buf(x)
                     acc = view_written(x)
                     x.written = True
+                    wrote(x, "pool")
                     assert y.gact is not None, "plan bug: pooled tensor has no gradient"
                     b.append(lambda a=a, gy=y.gact, gx=gx, acc=acc: ops.avgpool_bwd(gy, gx, a["stride"], acc))
                 elif rec.kind == "copy":
@@ -698,6 +727,7 @@ class Plan:
                     gx = self._grad_buf(x)
                     acc = view_written(x)
                     x.written = True
+                    wrote(x, "copy")
                     b.append(lambda gy=gy, gx=gx, acc=acc: ops.avgpool_bwd(gy, gx, (1, 1, 1), acc))
 
     def _grad_buf(self, at: AT):

@@ -373,3 +373,44 @@ def test_planar_concat_convs_equal_interleaved(ops, dtype):
         ops.conv3d_fwd(small, wf, None, ops.Act.empty(1, 4, 4, 16, 32, dtype), k, s)
     with pytest.raises(RxError):
         ops.instnorm_stats(planar, torch.empty((n, 64, 2), device="cuda"))              # every other entry point refuses cs != 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("slope", [0.01, 1.0])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_conv3d_bwd_data_instats(ops, dtype, slope, accumulate):
+    """rx_conv3d_bwd_data_instats: same dx as rx_conv3d_bwd_data bit for bit, and (mean g', mean g'*xhat) of the InstanceNorm
+    layer it completes equal to the two-pass reduction over the stored dx (fp64 on the host)"""
+    n, c, dims = 3, 32, (30, 36, 64)                       # >= 512 tiles of 4x4x16, ragged z / y: the persistent kernel
+    dyv = to_act(ops, rnd((n, c, *dims), dtype, seed=1, scale=0.2), dtype)
+    w = rnd((c, c, 3, 3, 3), torch.float32, seed=2, scale=0.1).float().cuda()
+    _, wb = ops.pack_conv_weight(w, dtype)
+    yv = to_act(ops, rnd((n, c, *dims), dtype, seed=3) + 0.3, dtype)
+    base = rnd((n, c, *dims), dtype, seed=5, scale=0.1)
+    dx1, dx2 = to_act(ops, base, dtype), to_act(ops, base, dtype)
+    stats = torch.empty((n, c, 2), device="cuda")
+    ops.instnorm_stats(yv, stats)
+    m12 = torch.full((n, c, 2), float("nan"), device="cuda")
+    k, s = (3, 3, 3), (1, 1, 1)
+    ops.conv3d_bwd_data(dyv, wb, dx1, k, s, accumulate)
+    fused = ops.conv3d_bwd_data_instats(dyv, wb, dx2, k, s, accumulate, yv, stats, slope, m12)
+    torch.cuda.synchronize()
+    assert fused, "the 32 -> 32 layer with >= 512 tiles must take the persistent kernel"
+    assert torch.equal(dx1.t, dx2.t)
+    g = dx1.to_ncdhw().double().cpu()
+    y = yv.to_ncdhw().double().cpu()
+    mean = stats[..., 0].double().cpu().view(n, c, 1, 1, 1)
+    rstd = stats[..., 1].double().cpu().view(n, c, 1, 1, 1)
+    xh = (y - mean) * rstd
+    if slope != 1.0:
+        g = torch.where(xh > 0, g, g * slope)
+    want = torch.stack([g.mean((2, 3, 4)), (g * xh).mean((2, 3, 4))], -1)
+    got = m12.double().cpu()
+    scale = want.abs().max().item()
+    assert torch.isfinite(got).all() and (got - want).abs().max().item() < 2e-4 * scale + 1e-7
+    dy1, dy2 = ops.Act.empty(n, *dims, c, dtype), ops.Act.empty(n, *dims, c, dtype)
+    ops.instnorm_act_bwd(dx1, yv, stats, None, dy1, slope)
+    ops.instnorm_act_bwd_apply(dx2, yv, stats, None, dy2, m12, slope)
+    torch.cuda.synchronize()
+    a_, b_ = dy2.tensor().double().cpu(), dy1.tensor().double().cpu()
+    assert ((a_ - b_).norm() / b_.norm()).item() < 3e-3
