@@ -314,7 +314,9 @@ def test_planar_concat_plan_matches_interleaved_plan(monkeypatch):
     equal the interleaved plan's (same kernels, same arithmetic, only the addressing of the concat halves differs)."""
     import mt3d_amd  # noqa: F401
     from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
-    tasks = {"sheet": {"channels": 1, "activation": "none", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
+    # two decoders: the second one's concat gets the skip by a copy into ITS planar buffer
+    tasks = {"sheet": {"channels": 1, "activation": "none", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}},
+             "normals": {"channels": 3, "activation": "none", "loss_fn": "MaskedCosineLoss"}}
     mgr = oracle.make_mgr((32, 32, 64), tasks, 1, 2, True, {})
     x, t = oracle.synthetic_batch(2, 1, (32, 32, 64), tasks, 5)
     res = {}
@@ -330,7 +332,9 @@ def test_planar_concat_plan_matches_interleaved_plan(monkeypatch):
         plan = next(iter(net._plans.values()))
         cats = [r.a["cat"].act for r in plan.dec_tapes[0] if r.kind == "convT"]
         assert any(c.is_planar_cat for c in cats) == (mode == "1")
-        res[mode] = (out["sheet"].detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+        assert all(c.is_planar_cat == (mode == "1") for tape in plan.dec_tapes for c in [r.a["cat"].act for r in tape if r.kind == "convT"][-1:])
+        res[mode] = (torch.cat([out["sheet"], out["normals"]], 1).detach().clone(),
+                     {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
     assert torch.equal(res["0"][0], res["1"][0])
     for n in res["0"][1]:
         assert torch.equal(res["0"][1][n], res["1"][1][n]), n
