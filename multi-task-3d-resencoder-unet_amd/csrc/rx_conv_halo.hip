@@ -258,7 +258,11 @@ __global__ __launch_bounds__(256) void ch_splitk_reduce(const float* __restrict_
 // lane_base + CONSTANT and folds into the ds_read_b128 offset field -- no address arithmetic in the MFMA loop
 // (the generic kernel above spends ~14 VALU instructions per MFMA on XOR-swizzled addresses).
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, bool FLIP>
+template <int NA>
+__device__ inline void ch_stat_flush(float (&s1)[NA][16], float (&s2)[NA][16], float* __restrict__ part, int n, int nchunks, int chunk, int Co,
+                                     int n0, int lane);      // (defined with the persistent kernels below)
+
+template <typename T, bool FLIP, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
                                                              T* __restrict__ out, const ConvHaloGeom g) {
   constexpr int P = Elem<T>::PER16;
@@ -387,6 +391,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict
     }
   }
 
+  float st1[1][16], st2[1][16];
+  if (STATS) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st1[0][r] = 0.f, st2[0][r] = 0.f;
+  }
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int v = (wave * 2 + b) * 32 + fv;
@@ -403,12 +412,23 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict
         if (bias) f += bias[n0 + co + i];
         if (g.accumulate) f += Elem<T>::to_f(op[co + i]);
         vals[i] = Elem<T>::from_f(f);
+        if (STATS) {
+          const float r = Elem<T>::to_f(vals[i]);
+          st1[0][4 * g4 + i] += r;
+          st2[0][4 * g4 + i] += r * r;
+        }
       }
       if (sizeof(T) == 2)
         *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
       else
         *reinterpret_cast<u32x4*>(op + co) = *reinterpret_cast<u32x4*>(vals);
     }
+  }
+  // STATS (deep layers only: one tile per workgroup, but hundreds of MFMAs per wave behind each wavefront reduction): the
+  // InstanceNorm sums of this wave's 64 voxels, partial row (tile of the sample, wave)
+  if (STATS) {
+    const int NTs = g.NT / g.N;
+    ch_stat_flush<1>(st1, st2, g.stat_part, n, NTs * 4, (tile - n * NTs) * 4 + wave, g.Co, n0, lane);
   }
 }
 
@@ -1133,7 +1153,14 @@ static void ch32_launch(dim3 grid, hipStream_t st, const void* in, const void* w
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  if (g.flip)
+  if (g.stat_part && !g.flip && !g.accumulate) {
+    static bool attr_s = false;
+    if (!attr_s) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo32_kernel<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_s = true;
+    }
+    hipLaunchKernelGGL((conv_halo32_kernel<T, false, true>), grid, dim3(256), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g);
+  } else if (g.flip)
     hipLaunchKernelGGL((conv_halo32_kernel<T, true>), grid, dim3(256), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g);
   else
     hipLaunchKernelGGL((conv_halo32_kernel<T, false>), grid, dim3(256), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g);
@@ -1315,6 +1342,12 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   if (BN == 32 && TZ == 4 && TY == 4 && TX == 16) {  // full-resolution layers: compile-time tile, padded rows
     if (out->cs) RX_FAIL(RX_EUNSUPPORTED, "conv_halo32: planar-concat output");
     rx_note_kernel("conv_halo32_kernel");
+    // statistics in the epilogue only for DEEP layers (>= 4 input-channel chunks: >= 432 MFMAs per wave behind the one wavefront
+    // reduction) with few tiles per sample (the finalize reads 4 partial rows per tile): the 16^3 layers
+    const int NTs32 = g.NT / g.N;
+    const bool fuse32n = stat_part && stat_chunks && !flip && !accumulate && dt != RX_F32 && g.Ci / KB >= 4 && NTs32 * 4 <= 1024 &&
+                         (size_t)g.N * NTs32 * 4 * 2 * g.Co * sizeof(float) <= stat_bytes;
+    g1.stat_part = fuse32n ? stat_part : nullptr;
     switch (dt) {
       case RX_F32: ch32_launch<float>(grid, st, in->ptr, w, bias, out->ptr, g1); break;
       case RX_BF16: ch32_launch<bf16_t>(grid, st, in->ptr, w, bias, out->ptr, g1); break;
@@ -1326,6 +1359,7 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
       rx_set_error("conv_halo32: %s", hipGetErrorString(e2));
       return RX_ELAUNCH;
     }
+    if (fuse32n) *stat_chunks = NTs32 * 4;
     return 1;
   }
   static int ch64ws = -1;   // RX_CH64WS: 0 off, 1 (default) on for layers with >= 256 (tile, channel block) pairs, 2 always

@@ -293,6 +293,8 @@ def test_error_paths(ops):
     (64, 64, (14, 32, 64)),      # conv_halo64ws: same, 64-channel block
     (64, 128, (8, 16, 32)),      # two channel blocks share the tiles
     (32, 64, (6, 10, 12)),       # not a persistent-kernel layer: conv followed by the separate statistics pass
+    (256, 256, (16, 16, 16)),    # deep layer on the one-tile-per-workgroup kernel: statistics from its epilogue too
+    (128, 96, (12, 16, 32)),     # same kernel (Co % 64 != 0), ragged z tiles
 ])
 def test_conv3d_fwd_stats(ops, dtype, case):
     """rx_conv3d_fwd_stats == rx_conv3d_fwd + rx_instnorm_stats: same y bit for bit, same (mean, rstd) to fp32 round-off"""
