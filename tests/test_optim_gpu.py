@@ -111,3 +111,31 @@ def test_clip_and_step_matches_clip_grad_norm_then_step():
             assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), it
             assert torch.allclose(a.grad, b.grad, rtol=2e-6, atol=1e-8)      # .grad holds the clipped gradient afterwards
     assert not hasattr(oa, "grad_scale") and not hasattr(oa, "found_inf")
+
+
+def test_engine_adamw_without_a_plan_clips_and_matches_torch():
+    """EngineAdamW(model=None): every parameter goes through rx_adamw_flat with the clip coefficient -- what bench.py runs"""
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.training.optim import EngineAdamW, clip_and_step
+    torch.manual_seed(1)
+    shapes = [(64, 32, 3, 3, 3), (64,), (7, 5), (128, 64, 1, 1, 1), (3, 32, 1, 1, 1)]
+    pa = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = EngineAdamW(pa, model=None, lr=1e-2, weight_decay=0.01)
+    ob = torch.optim.AdamW(pb, lr=1e-2, weight_decay=0.01, fused=True)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(oa, T_max=4)
+    sched_b = torch.optim.lr_scheduler.CosineAnnealingLR(ob, T_max=4)
+    for it in range(4):
+        scale = 10.0 if it % 2 == 0 else 0.01
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a) * scale
+            a.grad, b.grad = g.clone(), g.clone()
+        na = clip_and_step(oa, pa, 3)
+        nb = torch.nn.utils.clip_grad_norm_(pb, 3)
+        ob.step()
+        sched.step(); sched_b.step()
+        assert abs(float(na) - float(nb)) <= 1e-5 * float(nb)
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=3e-6, atol=3e-7), it
+    sd = oa.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}

@@ -91,7 +91,8 @@ def test_training_from_zarr_volumes_with_squeeze_excite(tmp_path):
     zarr_lite.write_array(str(tmp_path / "sheet.zarr"), (sheet * 255).astype(np.uint8), (32, 32, 32), compressor="zlib")
     cfg = yaml.safe_load(open(CFG))
     cfg["tr_setup"].update(model_name="zarr_se", ckpt_out_base=str(tmp_path / "ckpt"), tensorboard_log_dir=str(tmp_path / "tb"))
-    cfg["tr_config"].update(max_epoch=3, max_steps_per_epoch=8, max_val_steps_per_epoch=1, patch_size=[32, 32, 32])
+    cfg["tr_config"].update(max_epoch=3, max_steps_per_epoch=8, max_val_steps_per_epoch=1, patch_size=[32, 32, 32],
+                            engine_optimizer=True)          # the engine's AdamW kernel behind the optimizer hook
     cfg["model_config"] = {"conv_bias": False, "squeeze_excitation": True}
     cfg["dataset_config"].update(synthetic=False, min_labeled_ratio=0.05, min_bbox_percent=0.5, use_cache=True,
                                  cache_folder=str(tmp_path / "cache"),
@@ -112,6 +113,8 @@ def test_training_from_zarr_volumes_with_squeeze_excite(tmp_path):
     tr = Rec(str(p), verbose=False)
     from mt3d_amd.dataloading.dataset import ZarrSegmentationDataset3D
     assert isinstance(tr._configure_dataset(), ZarrSegmentationDataset3D)
+    from mt3d_amd.training.optim import EngineAdamW
+    assert isinstance(tr._get_optimizer(tr._build_model().cuda()), EngineAdamW)
     model = tr.train()
     assert any("squeeze_excitation.fc1.weight" in k for k in model.state_dict())
     assert len(tr.losses) == 3 and tr.losses[-1] < tr.losses[0]
