@@ -229,6 +229,10 @@ int rx_adamw_pack(rx_dtype dt, float* p, const float* grad, float* exp_avg, floa
                   void* w_fwd, void* w_bwd, void* stream);
 int rx_adamw_flat(float* p, const float* grad, float* exp_avg, float* exp_avg_sq, const float* clip, double lr, double beta1,
                   double beta2, double eps, double weight_decay, int step, long n, void* stream);
+/* the same for `count` tensors of one param group (shared hyper-parameters and step): HOST arrays of device pointers */
+int rx_adamw_flat_multi(int count, float* const* p, const float* const* grad, float* const* exp_avg,
+                        float* const* exp_avg_sq, const long* numel, const float* clip, double lr, double beta1,
+                        double beta2, double eps, double weight_decay, int step, void* stream);
 
 #ifdef __cplusplus
 }

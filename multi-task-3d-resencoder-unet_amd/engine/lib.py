@@ -93,6 +93,8 @@ _SIGNATURES = {
     "rx_masked_cosine_loss_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rx_adamw_pack": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_double,
                               c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rx_adamw_flat_multi": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double,
+                                    c_double, c_double, c_int, c_void_p]),
     "rx_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_double, c_int,
                               c_long, c_void_p]),
 }

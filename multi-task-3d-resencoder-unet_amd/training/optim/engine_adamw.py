@@ -14,6 +14,7 @@ torch's AdamW arithmetic (decoupled weight decay, bias correction), but its `ste
 Arithmetic is fp32 like torch's fused kernel; results agree with `torch.optim.AdamW(fused=True)` to fp32 round-off
 (tests/test_optim_gpu.py), not bit for bit (different FMA contraction).  CPU parameters are refused: this optimizer only
 exists for the engine."""
+import ctypes
 from ctypes import c_void_p
 
 import torch
@@ -65,6 +66,7 @@ class EngineAdamW(torch.optim.Optimizer):
         self._clip = None
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            flat = []                      # un-packed parameters of this group: one C call for all of them (rx_adamw_flat_multi)
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -88,6 +90,17 @@ class EngineAdamW(torch.optim.Optimizer):
                     ent["version"], ent["ptr"], ent["event"] = p._version, p.data_ptr(), None
                     ent["epoch"] = getattr(plan.net, "_weights_epoch", 0)
                 else:
-                    check(lib.rx_adamw_flat(_p(p), _p(g), _p(st["exp_avg"]), _p(st["exp_avg_sq"]), _p(clip), group["lr"], b1, b2,
-                                            group["eps"], group["weight_decay"], st["step"], p.numel(), stream_ptr()), "rx_adamw_flat")
+                    flat.append((p, g, st))
+            # tensors that share the step count go in one call (normally all of them)
+            by_step = {}
+            for p, g, st in flat:
+                by_step.setdefault(st["step"], []).append((p, g, st))
+            for step_no, items in by_step.items():
+                n = len(items)
+                VP, LP = ctypes.c_void_p * n, ctypes.c_long * n
+                check(lib.rx_adamw_flat_multi(n, VP(*[p.data_ptr() for p, _, _ in items]), VP(*[g.data_ptr() for _, g, _ in items]),
+                                              VP(*[st["exp_avg"].data_ptr() for _, _, st in items]),
+                                              VP(*[st["exp_avg_sq"].data_ptr() for _, _, st in items]),
+                                              LP(*[p.numel() for p, _, _ in items]), _p(clip), group["lr"], b1, b2, group["eps"],
+                                              group["weight_decay"], step_no, stream_ptr()), "rx_adamw_flat_multi")
         return loss

@@ -13,7 +13,8 @@ torch.manual_seed(0)
 net = NetworkFromConfig(bench.make_mgr(w)).cuda(); net.compute_dtype = torch.bfloat16; net.train()
 loss_fn = LOSS_FN_MAP["BCEDiceLoss"](0.5, 0.5)
 params = list(net.parameters())
-opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.0, fused=True)
+from mt3d_amd.training.optim import EngineAdamW, clip_and_step
+opt = EngineAdamW(params, model=None, lr=1e-3, weight_decay=0.0)
 x, t = bench.synthetic_batch(w, 2, 1234, "cuda")
 E = lambda: torch.cuda.Event(enable_timing=True)
 rec = []
@@ -32,7 +33,7 @@ def step(i, probe):
     r["e_fwd"].record()
     loss = loss_fn(out["sheet"], t["sheet"]); loss.backward()
     r["e_bwd"].record()
-    torch.nn.utils.clip_grad_norm_(params, 3); opt.step(); opt.zero_grad(set_to_none=True)
+    clip_and_step(opt, params, 3); opt.zero_grad(set_to_none=True)
     r["e_end"].record()
     r["h1"] = time.perf_counter()
     rec.append(r)
