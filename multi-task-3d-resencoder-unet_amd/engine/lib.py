@@ -137,5 +137,13 @@ def require_device():
         raise RxError("current HIP device is not gfx950")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream.  The raw getter skips building a torch.cuda.Stream object (~5 us, on
+    ~2000 enqueues per train step)."""
+    if _raw_stream is not None and _cur_device is not None:
+        return c_void_p(_raw_stream(_cur_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)

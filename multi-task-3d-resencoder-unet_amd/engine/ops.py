@@ -70,7 +70,7 @@ def workspace(nbytes=None, device=None):
 
 
 class Act:
-    __slots__ = ("t", "c0", "c", "root", "plane")
+    __slots__ = ("t", "c0", "c", "root", "plane", "_d")
 
     def __init__(self, t, c0=0, c=None):
         assert t.dim() == 5 and t.is_contiguous(), "Act wraps a contiguous (n,z,y,x,ld) tensor"
@@ -78,6 +78,7 @@ class Act:
         self.c = t.shape[4] - c0 if c is None else c
         assert 0 < self.c and c0 + self.c <= t.shape[4]
         self.root, self.plane = None, None      # set for planar concats and their planes (see `planar`)
+        self._d = None                          # cached rx_act descriptor (the wrapped storage never moves)
 
     @staticmethod
     def planar(root, plane=None):
@@ -135,10 +136,15 @@ class Act:
         return s[1] * s[2] * s[3]
 
     def desc(self):
-        s = self.t.shape
-        if self.is_planar_cat:
-            return RxAct(self.root.data_ptr(), s[0], s[1], s[2], s[3], self.c, 32, self.root.stride(0))
-        return RxAct(self.t.data_ptr() + self.c0 * self.t.element_size(), s[0], s[1], s[2], s[3], self.c, s[4], 0)
+        d = self._d
+        if d is None:       # built once: ~2 us of ctypes work per call otherwise, on ~2000 calls per train step
+            s = self.t.shape
+            if self.is_planar_cat:
+                d = RxAct(self.root.data_ptr(), s[0], s[1], s[2], s[3], self.c, 32, self.root.stride(0))
+            else:
+                d = RxAct(self.t.data_ptr() + self.c0 * self.t.element_size(), s[0], s[1], s[2], s[3], self.c, s[4], 0)
+            self._d = d
+        return d
 
     def like(self, root_or_t):
         """the same view (channel range / plane) of another buffer of the same shape (gradient buffers)"""
