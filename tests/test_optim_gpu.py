@@ -139,3 +139,29 @@ def test_engine_adamw_without_a_plan_clips_and_matches_torch():
             assert torch.allclose(a, b, rtol=3e-6, atol=3e-7), it
     sd = oa.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_engine_adamw_table_kernel_many_ragged_tensors():
+    """rx_adamw_flat_multi's table kernel: more tensors than one launch's table holds (48), sizes around the 4096-element
+    chunk (full chunks on 16-byte loads, ragged tails, tiny tensors) and a parameter whose storage is not 16-byte aligned."""
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.training.optim import EngineAdamW
+    torch.manual_seed(2)
+    sizes = [1, 3, 255, 4095, 4096, 4097, 8192, 12289, 70001] + [17 + 131 * i for i in range(50)]
+    base = torch.randn(40000, device="cuda")
+    odd = torch.nn.Parameter(base[1:1 + 20001])                   # data_ptr() % 16 == 4
+    assert odd.data_ptr() % 16 != 0
+    pa = [torch.nn.Parameter(torch.randn(n, device="cuda")) for n in sizes] + [odd]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = EngineAdamW(pa, model=None, lr=1e-2, weight_decay=0.01)
+    ob = torch.optim.AdamW(pb, lr=1e-2, weight_decay=0.01, fused=True)
+    for it in range(3):
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a)
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=3e-6, atol=3e-7), (it, a.numel())
+    assert torch.equal(base[0], base[0]) and torch.isfinite(base).all()
+    for a, b in zip(pa[:3], pb[:3]):
+        assert torch.allclose(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
