@@ -128,6 +128,8 @@ class Plan:
         import os
         # weight gradients on a side HIP stream (off the dependency chain); RX_OVERLAP_WGRAD=0 keeps one stream
         self.overlap_wgrad = os.environ.get("RX_OVERLAP_WGRAD", "1") != "0"
+        # dy slots per shape (RX_DY_RING): with 2 the main stream stalls whenever the side stream is more than one layer behind
+        self.dy_ring = max(2, int(os.environ.get("RX_DY_RING", "2")))
         self._side = None
         self._ws2 = None
         self._dy_turn: Dict[tuple, int] = {}
@@ -509,7 +511,7 @@ class Plan:
         of layer L (side stream) may still be reading its dy while layer L-1's backward already writes the next."""
         key = (y.act.dims, y.act.c)
         turn = self._dy_turn.get(key, 0)
-        self._dy_turn[key] = turn ^ 1
+        self._dy_turn[key] = (turn + 1) % self.dy_ring
         slot = key + (turn,)
         if slot not in self.dy_pool:
             t = torch.empty((*y.act.dims, y.act.c), dtype=self.dtype, device=self.device)
