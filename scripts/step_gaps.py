@@ -38,6 +38,16 @@ if i_bwd < i_opt:
     phase("backward", L[i_bwd:i_opt], L[i_bwd][0], L[i_opt][0] if i_opt < len(L) else t1)
 if i_opt < len(L):
     phase("optimize", L[i_opt:], L[i_opt][0], t1)
+def table(title, evs):
+    b = collections.defaultdict(list)
+    for e in evs:
+        b[e[3].split("(")[0][:70]].append((e[1] - e[0]) / 1e3)
+    print(title)
+    for n, d in sorted(b.items(), key=lambda kv: -sum(kv[1])):
+        print(f"  {sum(d):8.1f} us  {len(d):3d} x {sum(d) / len(d):7.1f}  {n}")
+if os.environ.get("STEP_GAPS_BWD"):
+    table("backward kernels of this step (main queue):", L[i_bwd:i_opt])
+    table("backward kernels of this step (other queues):", [e for e in step if e[2] != mainq and L[i_bwd][0] <= e[0] < (L[i_opt][0] if i_opt < len(L) else t1)])
 if os.environ.get("STEP_GAPS_FWD"):
     b = collections.defaultdict(list)
     for e in L[:i_bwd]:
