@@ -194,6 +194,13 @@ size_t rx_head_bwd_workspace(const rx_act* x, int k);
 int rx_head_bwd(rx_dtype dt, const float* dout_ncdhw, const rx_act* x, const float* w, int k, const rx_act* dx,
                 float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
 
+/* InstanceNorm + LeakyReLU backward of the layer that feeds a task head (the conv block of the last decoder stage,
+ * decoder.py:115-131: no residual), with the head's data gradient formed on the fly: g[v][c] = sum_k dout[k][v] * w[k][c] is
+ * never written (call rx_head_bwd with dx = NULL for dw / db).  Same dy, bit for bit, as rx_head_bwd(dx = g) followed by
+ * rx_instnorm_act_bwd(g, y, stats, out = NULL, ...).  k <= 4; ws as for rx_instnorm_act_bwd. */
+int rx_instnorm_act_bwd_head(rx_dtype dt, const float* dout_ncdhw, int k, const float* head_w, const rx_act* y,
+                             const float* stats, float slope, const rx_act* dy, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- per-channel sum over (n, voxels): bias gradients ----------------------------------- */
 size_t rx_channel_sum_workspace(const rx_act* x);
 int rx_channel_sum(rx_dtype dt, const rx_act* x, float* out, void* ws, size_t ws_bytes, void* stream);

@@ -1160,6 +1160,142 @@ extern "C" int rx_head_bwd(rx_dtype dt, const float* dout_ncdhw, const rx_act* x
   return RX_OK;
 }
 
+// ---- InstanceNorm backward of the layer that feeds a task head, with the head's data gradient formed on the fly ------
+// The gradient that reaches the last decoder conv block is rank K: g[v][c] = sum_k dlogit[k][v] * w_head[k][c] (K = 1 for a
+// segmentation head, 3 for normals).  rx_head_bwd used to write it as a full (N, V, C) tensor (268 MB at cfg2) that the two
+// passes of the InstanceNorm backward then read back twice.  Here both passes rebuild g from the fp32 logit gradient (4*K bytes
+// per voxel instead of 2*C) and the head's weights; rx_head_bwd is called with dx = NULL and only reduces dw / db.  g is
+// rounded to the storage type exactly where rx_head_bwd rounded it, so dy is bit-identical to the three-tensor path.
+#define RX_HEADG_MAXK 4
+template <typename T>
+struct InBwdHeadOp {
+  ActView<T> y;
+  const float* stats;
+  const float* dout;  // (N, K, V) fp32
+  const float* hw;    // (K, C)
+  int C, K, V;
+  float slope;
+  bool mask_xhat;
+  float mean[Elem<T>::PER16], rstd[Elem<T>::PER16], w[RX_HEADG_MAXK][Elem<T>::PER16];
+  __device__ inline void prepare(int n, int c0) {
+#pragma unroll
+    for (int j = 0; j < Elem<T>::PER16; ++j) {
+      mean[j] = stats[2 * ((size_t)n * C + c0 + j)];
+      rstd[j] = stats[2 * ((size_t)n * C + c0 + j) + 1];
+#pragma unroll
+      for (int k = 0; k < RX_HEADG_MAXK; ++k) w[k][j] = k < K ? hw[k * C + c0 + j] : 0.f;
+    }
+  }
+  __device__ inline void accumulate(int n, int v, int c0, float (&acc)[2][Elem<T>::PER16]) const {
+    constexpr int P = Elem<T>::PER16;
+    Vec16<T> yv = ld16(y.at(n, v, c0));
+    float d[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) d[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < RX_HEADG_MAXK; ++k)
+      if (k < K) {
+        const float gk = dout[((size_t)n * K + k) * V + v];
+#pragma unroll
+        for (int j = 0; j < P; ++j) d[j] += gk * w[k][j];
+      }
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      float gg = Elem<T>::to_f(Elem<T>::from_f(d[j]));
+      float xh = (Elem<T>::to_f(yv.v[j]) - mean[j]) * rstd[j];
+      if (mask_xhat && !(xh > 0.f)) gg *= slope;
+      acc[0][j] += gg;
+      acc[1][j] += gg * xh;
+    }
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void in_act_bwd_apply_head_kernel(const float* __restrict__ dout, int K, const float* __restrict__ hw,
+                                                                    const T* __restrict__ y, int ldy, long sy,
+                                                                    const float* __restrict__ stats, const float* __restrict__ m12,
+                                                                    T* __restrict__ dy, int lddy, long sdy, int V, int C, float slope,
+                                                                    int mask_xhat) {
+  constexpr int P = Elem<T>::PER16;
+  const int CV = C / P;
+  const int n = blockIdx.y;
+  const long total = (long)V * CV;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long step = (long)gridDim.x * 256;
+  const int cv = (int)(i % CV);
+  float mean[P], rstd[P], m1[P], m2[P], w[RX_HEADG_MAXK][P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    size_t k = (size_t)n * C + cv * P + j;
+    mean[j] = stats[2 * k];
+    rstd[j] = stats[2 * k + 1];
+    m1[j] = m12[2 * k];
+    m2[j] = m12[2 * k + 1];
+#pragma unroll
+    for (int q = 0; q < RX_HEADG_MAXK; ++q) w[q][j] = q < K ? hw[q * C + cv * P + j] : 0.f;
+  }
+  for (; i < total; i += step) {
+    long v = i / CV;
+    Vec16<T> yv = ld16(y + n * sy + v * ldy + cv * P);
+    float d[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) d[j] = 0.f;
+#pragma unroll
+    for (int q = 0; q < RX_HEADG_MAXK; ++q)
+      if (q < K) {
+        const float gk = dout[((size_t)n * K + q) * V + v];
+#pragma unroll
+        for (int j = 0; j < P; ++j) d[j] += gk * w[q][j];
+      }
+    Vec16<T> dv;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      float gg = Elem<T>::to_f(Elem<T>::from_f(d[j]));
+      float xh = (Elem<T>::to_f(yv.v[j]) - mean[j]) * rstd[j];
+      if (mask_xhat && !(xh > 0.f)) gg *= slope;
+      dv.v[j] = Elem<T>::from_f(rstd[j] * (gg - m1[j] - xh * m2[j]));
+    }
+    st16(dy + n * sdy + v * lddy + cv * P, dv);
+  }
+}
+
+// dy = InstanceNorm+LeakyReLU backward of a layer WITHOUT residual whose output gradient is the data gradient of a 1x1x1 head:
+// g = dout (N,K,Z,Y,X fp32) x head_w (K,C), never materialised.  Same result as rx_head_bwd(dx = g) + rx_instnorm_act_bwd(g, ...,
+// out = NULL).  K <= 4.
+extern "C" int rx_instnorm_act_bwd_head(rx_dtype dt, const float* dout_ncdhw, int k, const float* head_w, const rx_act* y,
+                                        const float* stats, float slope, const rx_act* dy, void* ws, size_t ws_bytes, void* stream) {
+  int rc;
+  if ((rc = check_vec_channels(y, dt, "rx_instnorm_act_bwd_head(y)"))) return rc;
+  if ((rc = check_vec_channels(dy, dt, "rx_instnorm_act_bwd_head(dy)"))) return rc;
+  if (!dout_ncdhw || !head_w || !stats || !ws || k < 1 || k > RX_HEADG_MAXK || !same_geom(y, dy))
+    RX_FAIL(RX_EINVAL, "rx_instnorm_act_bwd_head: bad arguments (K must be 1..%d)", RX_HEADG_MAXK);
+  const long V = rx_act_voxels(y);
+  const int N = y->n, C = y->c;
+  if (V > 0x7fffffffL) RX_FAIL(RX_EUNSUPPORTED, "rx_instnorm_act_bwd_head: volume too large");
+  size_t need = rx_reduce_ws_bytes(N, V, C, 2) + (size_t)N * C * 2 * sizeof(float);
+  if (ws_bytes < need) RX_FAIL(RX_EWORKSPACE, "rx_instnorm_act_bwd_head: workspace too small (%zu < %zu)", ws_bytes, need);
+  float* partial = (float*)ws;
+  float* m12 = (float*)((char*)ws + rx_align_up(rx_reduce_ws_bytes(N, V, C, 2) - 256, 256));
+  hipStream_t st = (hipStream_t)stream;
+  const bool mask_xhat = slope != 1.0f;
+  RX_DISPATCH_DTYPE(dt, T, {
+    constexpr int P = Elem<T>::PER16;
+    ReducePlan p = rx_reduce_plan(V, C, P);
+    int CV = C / P, VP = 256 / CV;
+    InBwdHeadOp<T> op{make_view<T>(y), stats, dout_ncdhw, head_w, C, k, (int)V, slope, mask_xhat, {}, {}, {}};
+    size_t lds = (size_t)2 * (VP > 4 ? VP : 4) * C * sizeof(float);
+    hipLaunchKernelGGL((colreduce_kernel<T, 2, InBwdHeadOp<T>>), dim3(p.nchunks, N), dim3(256), lds, st, op, (int)V, C, p.chunk_vox,
+                       partial);
+    hipLaunchKernelGGL(colreduce_finalize, dim3((N * C + 3) / 4), dim3(256), 0, st, (const float*)partial, N, p.nchunks, 2, C,
+                       (double)V, 0.f, (int)FIN_MEAN2, m12);
+    int G = sweep_grid(V * CV, CV);
+    hipLaunchKernelGGL((in_act_bwd_apply_head_kernel<T>), dim3(G, N), dim3(256), 0, st, dout_ncdhw, k, head_w, (const T*)y->ptr, y->ld,
+                       V * y->ld, stats, (const float*)m12, (T*)dy->ptr, dy->ld, V * dy->ld, (int)V, C, slope, mask_xhat ? 1 : 0);
+  });
+  RX_CHECK_LAUNCH("rx_instnorm_act_bwd_head");
+  return RX_OK;
+}
+
 // ---- stem convolution on the NCDHW fp32 image (Cin <= 4) ------------------------------------
 // thread -> (voxel, vector of P output channels); weights in LDS as [tap*Cin][Cout]
 template <typename T>

@@ -428,6 +428,14 @@ def head_bwd(dout_ncdhw, x, w, dx, dw, db, ws=None):
                              stream_ptr()), "rx_head_bwd")
 
 
+def instnorm_act_bwd_head(dout_ncdhw, w, y, stats, dy, slope=0.01, ws=None):
+    """InstanceNorm + LeakyReLU backward of the layer under a task head; the head's data gradient dout x w is formed on the fly
+    (head_bwd is then called with dx=None)"""
+    ws = workspace() if ws is None else ws
+    check(load().rx_instnorm_act_bwd_head(_code(y.dtype), _ptr(dout_ncdhw), w.shape[0], _ptr(w), byref(y.desc()), _ptr(stats),
+                                          float(slope), byref(dy.desc()), *_ws_args(ws), stream_ptr()), "rx_instnorm_act_bwd_head")
+
+
 def channel_sum(x, out, ws=None):
     ws = workspace() if ws is None else ws
     check(load().rx_channel_sum(_code(x.dtype), byref(x.desc()), _ptr(out), *_ws_args(ws), stream_ptr()),

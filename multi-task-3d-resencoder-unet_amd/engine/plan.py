@@ -583,9 +583,11 @@ class Plan:
                     assert not view_written(x)
                     gx = self._grad_buf(x)
                     x.written = True
-                    wrote(x, "head")
+                    hinfo = {"fused": False}      # set by the InstanceNorm step below when it rebuilds the head's data gradient itself
+                    wrote(x, "head", hinfo)
+                    a["hinfo"] = hinfo
 
-                    def step(a=a, gx=gx):
+                    def step(a=a, gx=gx, hinfo=hinfo):
                         dl = P._dlogits.get(a["name"])
                         if dl is None:      # this task did not take part in the loss
                             gx.t.zero_()
@@ -595,7 +597,7 @@ class Plan:
                                     done(i)
                             return
                         dw, db = new_grad(a["widx"]), new_grad(a["bidx"])
-                        ops.head_bwd(dl, a["x"].act, a["w"].view(a["k"], -1), gx, dw, db)
+                        ops.head_bwd(dl, a["x"].act, a["w"].view(a["k"], -1), None if hinfo["fused"] else gx, dw, db)
                         done(a["widx"])
                         done(a["bidx"])
                     order += [a["widx"], a["bidx"]]
@@ -614,6 +616,14 @@ class Plan:
                         res.written = True
                         wrote(res, "gres")
                     gw = getattr(out, "_gw", (None, None))
+                    # the layer under a task head (no residual): its output gradient is rank K -- rebuilt from the logit gradient
+                    # inside both InstanceNorm passes instead of written by the head and read back twice
+                    if (gw[0] == "head" and a["gate"] is None and res is None and self.dtype != torch.float32
+                            and out.act.voxels > 512 and os.environ.get("RX_FUSED_HEAD_BWD", "1") != "0"):
+                        heads = [r.a for r in tape if r.kind == "head" and r.a["x"] is out]
+                        if len(heads) == 1 and heads[0]["k"] <= 4:
+                            a["head_src"] = heads[0]
+                            gw[1]["fused"] = True
                     if (gw[0] == "conv" and a["gate"] is None and res is None and self.dtype != torch.float32
                             and out.act.full_buffer and out.act.root is None and out.act.c == 32 and out.act.voxels > 512
                             and out.act.dims[3] >= 16 and os.environ.get("RX_FUSED_BWD_STATS", "1") != "0"):
@@ -647,7 +657,11 @@ class Plan:
                         before_dy_write(dy)
                         # the saved output is only needed for the mask of residual blocks (sign(out) != sign(xhat) there)
                         mask_out = a["out"].act if (a["slope"] != 1.0 and a["res"] is not None) else None
-                        if a.get("m12_valid"):      # the two means came out of the backward-data kernel that completed gout
+                        hs = a.get("head_src")
+                        dl = P._dlogits.get(hs["name"]) if hs is not None else None   # None: task outside the loss, gout was zeroed
+                        if dl is not None:
+                            ops.instnorm_act_bwd_head(dl, hs["w"].view(hs["k"], -1), a["y"].act, a["stats"], dy, a["slope"])
+                        elif a.get("m12_valid"):      # the two means came out of the backward-data kernel that completed gout
                             a["m12_valid"] = False
                             ops.instnorm_act_bwd_apply(gout, a["y"].act, a["stats"], mask_out, dy, a["m12"], a["slope"], gres, acc)
                         else:

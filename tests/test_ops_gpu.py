@@ -416,3 +416,41 @@ def test_conv3d_bwd_data_instats(ops, dtype, slope, accumulate):
     torch.cuda.synchronize()
     a_, b_ = dy2.tensor().double().cpu(), dy1.tensor().double().cpu()
     assert ((a_ - b_).norm() / b_.norm()).item() < 3e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("k", [1, 3])
+@pytest.mark.parametrize("slope", [0.01, 1.0])
+def test_instnorm_act_bwd_head_is_head_bwd_then_instnorm_bwd(ops, dtype, k, slope):
+    """rx_instnorm_act_bwd_head rebuilds the head's data gradient g = dout x w inside both InstanceNorm passes: same dy, bit
+    for bit, as rx_head_bwd(dx = g) followed by rx_instnorm_act_bwd(g, ...); and against an fp64 torch reference"""
+    n, c, dims = 2, 32, (12, 20, 24)
+    V = dims[0] * dims[1] * dims[2]
+    y = to_act(ops, rnd((n, c, *dims), dtype, seed=21), dtype)
+    out = to_act(ops, rnd((n, c, *dims), dtype, seed=22), dtype)
+    dout = rnd((n, k, *dims), torch.float32, seed=23, scale=0.01).float().cuda().contiguous()
+    w = rnd((k, c), torch.float32, seed=24).float().cuda().contiguous()
+    stats = torch.empty((n, c, 2), device="cuda")
+    ops.instnorm_stats(y, stats)
+    g = ops.Act.empty(n, *dims, c, dtype)
+    dw, db = torch.empty((k, c), device="cuda"), torch.empty((k,), device="cuda")
+    dy1, dy2 = ops.Act.empty(n, *dims, c, dtype), ops.Act.empty(n, *dims, c, dtype)
+    ops.head_bwd(dout, out, w, g, dw, db)
+    ops.instnorm_act_bwd(g, y, stats, None, dy1, slope)
+    dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+    ops.head_bwd(dout, out, w, None, dw2, db2)
+    ops.instnorm_act_bwd_head(dout, w, y, stats, dy2, slope)
+    torch.cuda.synchronize()
+    assert torch.equal(dy1.t, dy2.t)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    # fp64 reference of the same arithmetic
+    yd = y.t.double()
+    mean, rstd = stats[..., 0].double().view(n, 1, 1, 1, c), stats[..., 1].double().view(n, 1, 1, 1, c)
+    xh = (yd - mean) * rstd
+    gd = torch.einsum("nkzyx,kc->nzyxc", dout.double(), w.double())
+    if slope != 1.0:
+        gd = torch.where(xh > 0, gd, gd * slope)
+    m1 = gd.mean(dim=(1, 2, 3), keepdim=True)
+    m2 = (gd * xh).mean(dim=(1, 2, 3), keepdim=True)
+    ref = rstd * (gd - m1 - xh * m2)
+    assert rel(dy2.t.float().cpu(), ref.float().cpu()) < (6e-3 if dtype == torch.bfloat16 else 8e-4)
