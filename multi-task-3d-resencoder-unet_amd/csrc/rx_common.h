@@ -36,6 +36,19 @@ void rx_note_kernel(const char* name);   // records which kernel instantiation t
   } while (0)
 
 // what a backward-data launch needs to know about the InstanceNorm layer (without residual) whose output gradient it completes
+// Epilogue stores of the 32x32 MFMA accumulator layout: lane l < 32 and lane l + 32 hold 8-byte pieces of the SAME voxel at
+// channels 8*g4 + 4*fh.  One v_permlane32_swap per dword (piece g4 of the upper half <-> piece g4+1 of the lower half) turns
+// two 8-byte pieces per lane into ONE 16-byte piece: the lower lane gets channels [8*g4, 8*g4+8), the upper lane
+// [8*g4+8, 8*g4+16) -- half as many store instructions, 32 contiguous bytes per voxel and instruction instead of 16.
+#ifndef RX_ST16
+#define RX_ST16 1
+#endif
+__device__ inline u32x4 rx_pair16(u32x2 a, u32x2 b) {
+  auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+  auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+  return u32x4{r0[0], r1[0], r0[1], r1[1]};
+}
+
 struct RxBwdStat {
   const rx_act* y;      // saved conv output of that layer
   const float* stats;   // its (mean, rstd)
