@@ -238,7 +238,10 @@ def main():
         for name, gt in targets.items():
             loss = loss + loss_fns[name](out[name], gt) * w["tasks"][name].get("weight", 1.0)
         loss.backward()
-        if stepper is not None and not engine_opt:
+        if stepper is not None and engine_opt:
+            opt.clip_grad_norm(3)                 # norm only: the coefficient is applied inside the streamed update kernels
+            stepper.step()
+        elif stepper is not None:
             torch.nn.utils.clip_grad_norm_(params, 3)
             stepper.step()
         elif fused_clip or engine_opt:

@@ -30,9 +30,16 @@ class StreamedOptimizerStep:
         self.model = model
         self.chunk_bytes = int(chunk_bytes)
         self._warm = False
+        self._clip = None
 
     # ------------------------------------------------------------------------------------------------------------
+    def _engine_opt(self):
+        from ..training.optim.engine_adamw import EngineAdamW
+        return isinstance(self.opt, EngineAdamW) and self.opt.model is None
+
     def _supported(self):
+        if self._engine_opt():        # the engine's AdamW (flat mode): clip coefficient inside the update, no state warm-up needed
+            return True
         if not isinstance(self.opt, (torch.optim.Adam, torch.optim.AdamW)):
             return False
         for g in self.opt.param_groups:
@@ -51,6 +58,12 @@ class StreamedOptimizerStep:
     # ------------------------------------------------------------------------------------------------------------
     def step(self):
         plans = self._train_plans()
+        engine = self._engine_opt()
+        if engine and (len(plans) != 1 or plans[0]._side is None):
+            self.opt.step()
+            return
+        if engine:
+            self._warm = True
         if not self._supported() or len(plans) != 1 or plans[0]._side is None or not self._warm:
             # first step (optimizer state not initialised yet), unsupported optimizer, or no single training plan
             self.opt.step()
@@ -63,7 +76,8 @@ class StreamedOptimizerStep:
             for p in g["params"]:
                 group_of[id(p)] = g
         with_grad = [p for g in self.opt.param_groups for p in g["params"] if p.grad is not None]
-        if any(p not in self.opt.state or "exp_avg" not in self.opt.state[p] for p in with_grad):
+        self._clip = self.opt.take_clip() if engine else None
+        if not engine and any(p not in self.opt.state or "exp_avg" not in self.opt.state[p] for p in with_grad):
             self.opt.step()                               # a parameter got its first gradient: let torch create its state
             return
         packed = {id(e["param"]): e for e in plan.packs}
@@ -89,12 +103,18 @@ class StreamedOptimizerStep:
             for chunk in chunks:
                 self._adam(chunk, group_of)
                 plan.repack([packed[id(p)] for p in chunk])
+        if self._clip is not None:
+            self._clip.record_stream(side)
+            self._clip = None
         for p in with_grad:
             p.grad.record_stream(side)                    # zero_grad(set_to_none=True) may free it while the side stream reads
         self.opt._opt_called = True                       # what torch's lr schedulers look at
 
     def _adam(self, params, group_of):
         if not params:
+            return
+        if self._engine_opt():
+            self.opt.update_subset(params, self._clip)    # one table-kernel launch per <= 48 tensors (rx_adamw_flat_multi)
             return
         from torch.optim.adam import adam
         by_group = {}

@@ -91,16 +91,48 @@ class EngineAdamW(torch.optim.Optimizer):
                     ent["epoch"] = getattr(plan.net, "_weights_epoch", 0)
                 else:
                     flat.append((p, g, st))
-            # tensors that share the step count go in one call (normally all of them)
-            by_step = {}
-            for p, g, st in flat:
-                by_step.setdefault(st["step"], []).append((p, g, st))
-            for step_no, items in by_step.items():
-                n = len(items)
-                VP, LP = ctypes.c_void_p * n, ctypes.c_long * n
-                check(lib.rx_adamw_flat_multi(n, VP(*[p.data_ptr() for p, _, _ in items]), VP(*[g.data_ptr() for _, g, _ in items]),
-                                              VP(*[st["exp_avg"].data_ptr() for _, _, st in items]),
-                                              VP(*[st["exp_avg_sq"].data_ptr() for _, _, st in items]),
-                                              LP(*[p.numel() for p, _, _ in items]), _p(clip), group["lr"], b1, b2, group["eps"],
-                                              group["weight_decay"], step_no, stream_ptr()), "rx_adamw_flat_multi")
+            self._flat_update(group, flat, clip)
         return loss
+
+    def _flat_update(self, group, items, clip):
+        """items: (param, grad, state) of ONE param group, state["step"] already advanced -> rx_adamw_flat_multi on the current stream
+        (tensors that share the step count go in one call: normally all of them)"""
+        b1, b2 = group["betas"]
+        by_step = {}
+        for p, g, st in items:
+            by_step.setdefault(st["step"], []).append((p, g, st))
+        for step_no, its in by_step.items():
+            n = len(its)
+            VP, LP = ctypes.c_void_p * n, ctypes.c_long * n
+            check(load().rx_adamw_flat_multi(n, VP(*[p.data_ptr() for p, _, _ in its]), VP(*[g.data_ptr() for _, g, _ in its]),
+                                             VP(*[st["exp_avg"].data_ptr() for _, _, st in its]),
+                                             VP(*[st["exp_avg_sq"].data_ptr() for _, _, st in its]),
+                                             LP(*[p.numel() for p, _, _ in its]), _p(clip), group["lr"], b1, b2, group["eps"],
+                                             group["weight_decay"], step_no, stream_ptr()), "rx_adamw_flat_multi")
+
+    # ---- pieces of step() for engine/streamed_step.py: the same update for a SUBSET of the parameters, on the current stream ----
+    def take_clip(self):
+        """the device scalar left by clip_grad_norm() (None if it was not called); consumed"""
+        clip, self._clip = self._clip, None
+        return clip
+
+    @torch.no_grad()
+    def update_subset(self, params, clip):
+        group_of = {id(p): g for g in self.param_groups for p in g["params"]}
+        per_group = {}
+        for p in params:
+            if p.grad is None:
+                continue
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise _l.RxError("EngineAdamW updates contiguous fp32 parameters on the HIP device only")
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            st = self.state[p]
+            if not st:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st["step"] = int(st["step"]) + 1
+            grp = group_of[id(p)]
+            per_group.setdefault(id(grp), (grp, []))[1].append((p, g, st))
+        for grp, items in per_group.values():
+            self._flat_update(grp, items, clip)

@@ -338,3 +338,51 @@ def test_planar_concat_plan_matches_interleaved_plan(monkeypatch):
     assert torch.equal(res["0"][0], res["1"][0])
     for n in res["0"][1]:
         assert torch.equal(res["0"][1][n], res["1"][1][n]), n
+
+
+def test_streamed_engine_adamw_is_bit_identical(NetworkFromConfig):
+    """StreamedOptimizerStep over EngineAdamW (flat mode): clip coefficient + AdamW table kernel per chunk on the side stream, re-pack
+    behind it, next forward waits per parameter -> same parameters and losses, bit for bit, as clip_and_step() on the main stream"""
+    from mt3d_amd.engine.streamed_step import StreamedOptimizerStep
+    from mt3d_amd.training.optim import EngineAdamW, clip_and_step
+    c = CASES["auto16_2head"]
+
+    def run(streamed):
+        net, _, _ = build(NetworkFromConfig, "auto16_2head")
+        x, targets = oracle.synthetic_batch(c["batch"], c["in_channels"], c["patch"], c["tasks"], 7)
+        x = x.cuda()
+        targets = {k: v.cuda() for k, v in targets.items()}
+        params = [p for p in net.parameters()]
+        opt = EngineAdamW(params, model=None, lr=1e-2, weight_decay=0.01)
+        stepper = StreamedOptimizerStep(opt, net, chunk_bytes=1 << 16) if streamed else None
+        losses, evals = [], []
+        for step in range(5):
+            net.train()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = net(x)
+            loss = oracle.train_loss(out, targets, c["tasks"])
+            loss.backward()
+            if streamed:
+                opt.clip_grad_norm(0.5)             # small max_norm: the coefficient is active
+                stepper.step()
+            else:
+                clip_and_step(opt, params, 0.5)
+            opt.zero_grad(set_to_none=True)
+            losses.append(loss.item())
+            if step == 2:
+                net.eval()
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                    evals.append({k: v.clone() for k, v in net(x).items()})
+        if streamed:
+            stepper.synchronize()
+        torch.cuda.synchronize()
+        return losses, evals, {n: p.detach().clone() for n, p in net.named_parameters()}
+
+    l_a, e_a, p_a = run(False)
+    l_b, e_b, p_b = run(True)
+    assert l_a == l_b
+    for a, b in zip(e_a, e_b):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    for n in p_a:
+        assert torch.equal(p_a[n], p_b[n]), n
