@@ -236,6 +236,13 @@ int rx_adamw_pack(rx_dtype dt, float* p, const float* grad, float* exp_avg, floa
                   void* w_fwd, void* w_bwd, void* stream);
 int rx_adamw_flat(float* p, const float* grad, float* exp_avg, float* exp_avg_sq, const float* clip, double lr, double beta1,
                   double beta2, double eps, double weight_decay, int step, long n, void* stream);
+/* Global L2 norm of a list of fp32 gradient tensors and the clip coefficient of torch.nn.utils.clip_grad_norm_(params,
+ * max_norm) (train.py:227) in two launches: out[0] = norm, out[1] = min(1, max_norm / (norm + 1e-6)); the coefficient is what
+ * rx_adamw_flat(_multi) / rx_adamw_pack take as `clip`.  Deterministic (fixed summation order).  `partial`: device scratch of
+ * rx_grad_norm_clip_partials(count, numel) floats.  Pointer arrays are host arrays. */
+long rx_grad_norm_clip_partials(int count, const long* numel);
+int rx_grad_norm_clip(int count, const float* const* grad, const long* numel, float max_norm, float* partial, long partial_len,
+                      float* out, void* stream);
 /* the same for `count` tensors of one param group (shared hyper-parameters and step): HOST arrays of device pointers */
 int rx_adamw_flat_multi(int count, float* const* p, const float* const* grad, float* const* exp_avg,
                         float* const* exp_avg_sq, const long* numel, const float* clip, double lr, double beta1,

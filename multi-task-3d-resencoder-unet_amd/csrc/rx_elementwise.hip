@@ -1930,6 +1930,104 @@ extern "C" int rx_adamw_flat_multi(int count, float* const* p, const float* cons
   return RX_OK;
 }
 
+// ---- global gradient norm + clip coefficient (torch.nn.utils.clip_grad_norm_, train.py:227) as two launches ---------------
+// torch's path is _foreach_norm (one multi-tensor launch per ~20 tensors: 10 launches of 24 us at cfg2) + stack + vector_norm +
+// the scalar arithmetic of the coefficient: ~20 launches at the serial end of a step.  Here: the AdamW table layout (48 tensors
+// per launch, one workgroup per 4096 elements) writes one fp32 sum of squares per workgroup, and a single workgroup adds them
+// in fp64 in a fixed order (deterministic) and leaves (norm, min(1, max_norm / (norm + 1e-6))) behind.
+struct SqnormMulti {
+  const float* g[RX_AM_MAX];
+  long n[RX_AM_MAX];
+  int start[RX_AM_MAX + 1];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void sqnorm_multi_kernel(const SqnormMulti t, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  int lo = 0, hi = t.count;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (t.start[mid] <= b) lo = mid; else hi = mid;
+  }
+  const long base = (long)(b - t.start[lo]) * RX_AM_CHUNK;
+  const long n = t.n[lo];
+  const float* __restrict__ g = t.g[lo];
+  float s = 0.f;
+  if ((((uintptr_t)g) & 15) == 0 && base + RX_AM_CHUNK <= n) {
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(g + base + (long)(j * 256 + threadIdx.x) * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += v[j][k] * v[j][k];
+  } else {
+    const long end = base + RX_AM_CHUNK < n ? base + RX_AM_CHUNK : n;
+    for (long i = base + threadIdx.x; i < end; i += 256) s += g[i] * g[i];
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[b] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sqnorm_finalize_kernel(const float* __restrict__ partial, int nblocks, float max_norm,
+                                                              float* __restrict__ out /* [2]: norm, clip coefficient */) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(red[0]);
+    const float coef = max_norm / (norm + 1e-6f);
+    out[0] = norm;
+    out[1] = coef < 1.f ? coef : 1.f;
+  }
+}
+
+// number of fp32 partials rx_grad_norm_clip needs for these tensor sizes
+extern "C" long rx_grad_norm_clip_partials(int count, const long* numel) {
+  long blocks = 0;
+  for (int i = 0; i < count; ++i) blocks += (numel[i] + RX_AM_CHUNK - 1) / RX_AM_CHUNK;
+  return blocks;
+}
+
+// out[0] = || (g_0, ..., g_{count-1}) ||_2, out[1] = min(1, max_norm / (out[0] + 1e-6)).  `partial`: device scratch of
+// rx_grad_norm_clip_partials() floats.  Pointer arrays are HOST arrays.
+extern "C" int rx_grad_norm_clip(int count, const float* const* grad, const long* numel, float max_norm, float* partial, long partial_len,
+                                 float* out, void* stream) {
+  if (count < 1 || !grad || !numel || !partial || !out) RX_FAIL(RX_EINVAL, "rx_grad_norm_clip: bad arguments");
+  const long need = rx_grad_norm_clip_partials(count, numel);
+  if (need > partial_len || need > 0x3fffffffL) RX_FAIL(RX_EWORKSPACE, "rx_grad_norm_clip: %ld partials needed, %ld given", need, partial_len);
+  long done = 0;
+  for (int i0 = 0; i0 < count;) {
+    SqnormMulti t;
+    int k = 0;
+    long blocks = 0;
+    for (; i0 + k < count && k < RX_AM_MAX; ++k) {
+      if (!grad[i0 + k] || numel[i0 + k] < 1) RX_FAIL(RX_EINVAL, "rx_grad_norm_clip: bad tensor %d", i0 + k);
+      t.g[k] = grad[i0 + k], t.n[k] = numel[i0 + k];
+      t.start[k] = (int)blocks;
+      blocks += (numel[i0 + k] + RX_AM_CHUNK - 1) / RX_AM_CHUNK;
+    }
+    for (int q = k; q <= RX_AM_MAX; ++q) t.start[q] = (int)blocks;
+    for (int q = k; q < RX_AM_MAX; ++q) t.g[q] = nullptr, t.n[q] = 0;
+    t.count = k;
+    hipLaunchKernelGGL(sqnorm_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, partial + done);
+    done += blocks;
+    i0 += k;
+  }
+  hipLaunchKernelGGL(sqnorm_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, (int)done, max_norm, out);
+  RX_CHECK_LAUNCH("rx_grad_norm_clip");
+  return RX_OK;
+}
+
 static int pack_generic(rx_dtype dt, const float* w, int A, int B, int TT, void* same, int flip_same, void* swp, int flip_swap,
                         void* stream) {
   if (!w || A < 1 || B < 1 || TT < 1 || TT > 27) RX_FAIL(RX_EINVAL, "rx_pack: bad arguments");

@@ -15,6 +15,7 @@ Arithmetic is fp32 like torch's fused kernel; results agree with `torch.optim.Ad
 (tests/test_optim_gpu.py), not bit for bit (different FMA contraction).  CPU parameters are refused: this optimizer only
 exists for the engine."""
 import ctypes
+import os
 from ctypes import c_void_p
 
 import torch
@@ -33,6 +34,7 @@ class EngineAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self.model = model            # NetworkFromConfig whose training plan's packs are rewritten (optional)
         self._clip = None             # device scalar set by clip_grad_norm(), consumed by the next step()
+        self._norm_ws = None          # scratch of rx_grad_norm_clip
 
     # ---- gradient clipping without touching the gradients -------------------------------------------------------
     @torch.no_grad()
@@ -41,6 +43,20 @@ class EngineAdamW(torch.optim.Optimizer):
         grads = [p.grad for g in self.param_groups for p in g["params"] if p.grad is not None]
         if not grads:
             return torch.zeros(())
+        if (float(norm_type) == 2.0 and os.environ.get("RX_ENGINE_GRAD_NORM", "1") != "0"
+                and all(g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() for g in grads)):
+            # two launches (table kernel + one-workgroup finalize) instead of torch's ~20: norm AND coefficient on the device
+            n = len(grads)
+            VP, LP = ctypes.c_void_p * n, ctypes.c_long * n
+            numel = LP(*[g.numel() for g in grads])
+            need = load().rx_grad_norm_clip_partials(n, numel)
+            if self._norm_ws is None or self._norm_ws.numel() < need or self._norm_ws.device != grads[0].device:
+                self._norm_ws = torch.empty(int(need), dtype=torch.float32, device=grads[0].device)
+            out = torch.empty(2, dtype=torch.float32, device=grads[0].device)
+            check(load().rx_grad_norm_clip(n, VP(*[g.data_ptr() for g in grads]), numel, float(max_norm), _p(self._norm_ws),
+                                           self._norm_ws.numel(), _p(out), stream_ptr()), "rx_grad_norm_clip")
+            self._clip = out[1:2]
+            return out[0]
         norms = torch._foreach_norm(grads, norm_type)
         total = torch.linalg.vector_norm(torch.stack(norms), norm_type)
         self._clip = torch.clamp(max_norm / (total + 1e-6), max=1.0).to(torch.float32).reshape(1)

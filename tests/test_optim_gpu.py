@@ -165,3 +165,29 @@ def test_engine_adamw_table_kernel_many_ragged_tensors():
     assert torch.equal(base[0], base[0]) and torch.isfinite(base).all()
     for a, b in zip(pa[:3], pb[:3]):
         assert torch.allclose(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+
+
+def test_engine_grad_norm_clip_matches_torch():
+    """rx_grad_norm_clip (EngineAdamW.clip_grad_norm): global L2 norm and min(1, max_norm / (norm + 1e-6)) over more tensors than one
+    table launch holds, ragged sizes and a 16-byte-misaligned gradient; deterministic"""
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.training.optim import EngineAdamW
+    torch.manual_seed(3)
+    sizes = [1, 5, 4095, 4096, 4097, 100003] + [31 + 97 * i for i in range(55)]
+    ps = [torch.nn.Parameter(torch.zeros(n, device="cuda")) for n in sizes]
+    base = torch.randn(9000, device="cuda")
+    for p in ps:
+        p.grad = torch.randn_like(p) * 0.3
+    ps.append(torch.nn.Parameter(torch.zeros(8191, device="cuda")))
+    ps[-1].grad = base[1:8192]
+    assert ps[-1].grad.data_ptr() % 16 != 0
+    opt = EngineAdamW(ps, model=None, lr=1e-3)
+    for max_norm in (3.0, 1e4):
+        ref = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(p.grad.double()) for p in ps])).item()
+        got = opt.clip_grad_norm(max_norm)
+        coef = opt._clip.clone()
+        got2 = opt.clip_grad_norm(max_norm)
+        assert got.item() == got2.item() and torch.equal(coef, opt._clip)          # fixed summation order
+        assert abs(got.item() - ref) <= 2e-6 * ref
+        assert abs(coef.item() - min(1.0, max_norm / (ref + 1e-6))) <= 3e-6
+        opt._clip = None
