@@ -1602,9 +1602,15 @@ extern "C" int rx_stem_conv_bwd_weight(rx_dtype dt, const float* x_ncdhw, int n,
 // eight 2-byte LDS reads + one 16-byte store.  (The first version stored every bf16 element with its own 2-byte global
 // store and two runtime integer divisions: 97 us per launch, 6.4 ms of kernel time per step.)
 #define RX_PACK_PB 40   // LDS pitch of a b-row in elements (80 bytes)
+// 1024 threads per tile: the load loop is one 16-byte load + four 2-byte LDS writes per iteration, so the loads in flight per
+// CU scale with the thread count (one workgroup per CU for the 512-channel weights: 256 tiles).  256 threads: 34 us per 7 M-parameter
+// weight; see DESIGN.md row ai
+#ifndef RX_PACK_THREADS
+#define RX_PACK_THREADS 1024
+#endif
 
 template <typename T>
-__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, int A, int B, int TT, unsigned inv_tt, T* __restrict__ same,
+__global__ __launch_bounds__(RX_PACK_THREADS) void pack_kernel(const float* __restrict__ w, int A, int B, int TT, unsigned inv_tt, T* __restrict__ same,
                                                    int flip_same, T* __restrict__ swp, int flip_swap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pack_smem[];
   T* L = reinterpret_cast<T*>(pack_smem);               // [TT][32 a][RX_PACK_PB]
@@ -1614,7 +1620,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
   // ---- load + convert + transpose into LDS
   if (full && TT > 1 && (rowlen & 3) == 0 && ((size_t)B * TT & 3) == 0) {
     const int q4 = rowlen >> 2;                           // float4 pieces per a-row
-    for (int q = threadIdx.x; q < 32 * q4; q += 256) {
+    for (int q = threadIdx.x; q < 32 * q4; q += RX_PACK_THREADS) {
       const int a = q / q4, c = q - a * q4;
       const f32x4 v = *reinterpret_cast<const f32x4*>(w + ((size_t)(a0 + a) * B + b0) * TT + 4 * c);
 #pragma unroll
@@ -1625,7 +1631,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
       }
     }
   } else {
-    for (int i = threadIdx.x; i < 32 * rowlen; i += 256) {
+    for (int i = threadIdx.x; i < 32 * rowlen; i += RX_PACK_THREADS) {
       const int a = i / rowlen, r = i - a * rowlen;
       const int b = r / TT, t = r - b * TT;
       float v = 0.f;
@@ -1636,7 +1642,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
   __syncthreads();
   if (full) {
     // ---- 16-byte stores: 4 vectors of 8 per (t, row)
-    for (int v = threadIdx.x; v < TT * 128; v += 256) {
+    for (int v = threadIdx.x; v < TT * 128; v += RX_PACK_THREADS) {
       const int t = v >> 7, rem = v & 127, row = rem >> 2, c8 = (rem & 3) * 8;
       if (same) {   // row = a, 8 consecutive b
         const int to = flip_same ? TT - 1 - t : t;
@@ -1653,7 +1659,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
     }
     return;
   }
-  for (int i = threadIdx.x; i < TT * 32 * 32; i += 256) {
+  for (int i = threadIdx.x; i < TT * 32 * 32; i += RX_PACK_THREADS) {
     const int t = i / 1024, r = i - t * 1024;
     {
       const int a = r >> 5, b = r & 31;
@@ -2036,7 +2042,7 @@ static int pack_generic(rx_dtype dt, const float* w, int A, int B, int TT, void*
     size_t lds = (size_t)TT * 32 * RX_PACK_PB * sizeof(T);
     const unsigned inv_tt = (unsigned)(((1ull << 32) + TT - 1) / TT);   // r / TT == umulhi(r, inv_tt) for r < 2^16
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((pack_kernel<T>), dim3((B + 31) / 32, (A + 31) / 32), dim3(256), lds, st, w, A, B, TT, inv_tt, (T*)same, flip_same, (T*)swp,
+    hipLaunchKernelGGL((pack_kernel<T>), dim3((B + 31) / 32, (A + 31) / 32), dim3(RX_PACK_THREADS), lds, st, w, A, B, TT, inv_tt, (T*)same, flip_same, (T*)swp,
                        flip_swap);
   });
   RX_CHECK_LAUNCH("rx_pack");
