@@ -194,6 +194,12 @@ size_t rx_head_bwd_workspace(const rx_act* x, int k);
 int rx_head_bwd(rx_dtype dt, const float* dout_ncdhw, const rx_act* x, const float* w, int k, const rx_act* dx,
                 float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
 
+/* InstanceNorm apply + LeakyReLU of the layer under a task head AND the head's 1x1x1 conv (+ eval-mode activation) in one pass:
+ * the activated output is written (skip of nothing, but the backward needs it) and not re-read.  Same `out` bit for bit and the same
+ * logits to fp32 round-off as rx_instnorm_act_fwd followed by rx_head_fwd (decoder.py:115-131,151-152).  16-bit types, k <= 4. */
+int rx_instnorm_act_head_fwd(rx_dtype dt, const rx_act* y, const float* stats, const rx_act* out, float slope,
+                             const float* head_w, const float* head_b, int k, float* out_ncdhw, int act, void* stream);
+
 /* InstanceNorm + LeakyReLU backward of the layer that feeds a task head (the conv block of the last decoder stage,
  * decoder.py:115-131: no residual), with the head's data gradient formed on the fly: g[v][c] = sum_k dout[k][v] * w[k][c] is
  * never written (call rx_head_bwd with dx = NULL for dw / db).  Same dy, bit for bit, as rx_head_bwd(dx = g) followed by

@@ -1160,13 +1160,120 @@ extern "C" int rx_head_bwd(rx_dtype dt, const float* dout_ncdhw, const rx_act* x
   return RX_OK;
 }
 
+#define RX_HEADG_MAXK 4
+// ---- InstanceNorm + LeakyReLU of the layer under a task head, with the head's 1x1x1 conv in the same pass -----------
+// rx_head_fwd re-read the activated output (268 MB at cfg2) to form K logits per voxel.  Here the CV lanes that hold one voxel's
+// channel vectors pass the running sums along (lane cv adds its channels to what lane cv-1 computed: the SAME order of fused
+// multiply-adds as head_fwd_kernel's loop over channels, from the rounded output values; logits agree to the last bit or two); the last lane
+// applies the eval-mode activation and writes the NCDHW fp32 logits.  K <= 4, no residual (decoder.py:115-131).
+template <typename T>
+__global__ __launch_bounds__(256) void in_act_head_fwd_kernel(const T* __restrict__ y, int ldy, long sy, const float* __restrict__ stats,
+                                                              T* __restrict__ out, int ldo, long so, int V, int C, float slope,
+                                                              const float* __restrict__ hw, const float* __restrict__ hb, int K,
+                                                              float* __restrict__ logits, int act) {
+  constexpr int P = Elem<T>::PER16;
+  const int CV = C / P;
+  const int n = blockIdx.y;
+  const long total = (long)V * CV;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long step = (long)gridDim.x * 256;
+  const int cv = (int)(i % CV);
+  float mean[P], rstd[P], w[RX_HEADG_MAXK][P], b[RX_HEADG_MAXK];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    mean[j] = stats[2 * ((size_t)n * C + cv * P + j)];
+    rstd[j] = stats[2 * ((size_t)n * C + cv * P + j) + 1];
+#pragma unroll
+    for (int k = 0; k < RX_HEADG_MAXK; ++k) w[k][j] = k < K ? hw[k * C + cv * P + j] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < RX_HEADG_MAXK; ++k) b[k] = k < K ? hb[k] : 0.f;
+  const T* yn = y + n * sy;
+  T* on = out + n * so;
+  for (; i < total; i += step) {
+    long v = i / CV;
+    Vec16<T> a = ld16(yn + v * ldy + cv * P);
+    Vec16<T> o;
+    float of[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      float f = (Elem<T>::to_f(a.v[j]) - mean[j]) * rstd[j];
+      f = f > 0.f ? f : f * slope;
+      o.v[j] = Elem<T>::from_f(f);
+      of[j] = Elem<T>::to_f(o.v[j]);
+    }
+    st16(on + v * ldo + cv * P, o);
+    float acc[RX_HEADG_MAXK];
+#pragma unroll
+    for (int k = 0; k < RX_HEADG_MAXK; ++k) acc[k] = b[k];
+    for (int s = 0; s < CV; ++s) {
+      float prev[RX_HEADG_MAXK];
+#pragma unroll
+      for (int k = 0; k < RX_HEADG_MAXK; ++k) prev[k] = __shfl_up(acc[k], 1, 64);
+      if (cv == s) {
+#pragma unroll
+        for (int k = 0; k < RX_HEADG_MAXK; ++k) {
+          float t = s == 0 ? b[k] : prev[k];
+#pragma unroll
+          for (int j = 0; j < P; ++j) t += of[j] * w[k][j];
+          acc[k] = t;
+        }
+      }
+    }
+    if (cv == CV - 1) {
+      if (act == RX_ACT_SIGMOID) {
+#pragma unroll
+        for (int k = 0; k < RX_HEADG_MAXK; ++k) acc[k] = 1.f / (1.f + expf(-acc[k]));
+      } else if (act == RX_ACT_SOFTMAX) {
+        float m = -INFINITY, sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < RX_HEADG_MAXK; ++k)
+          if (k < K) m = fmaxf(m, acc[k]);
+#pragma unroll
+        for (int k = 0; k < RX_HEADG_MAXK; ++k)
+          if (k < K) {
+            acc[k] = expf(acc[k] - m);
+            sum += acc[k];
+          }
+#pragma unroll
+        for (int k = 0; k < RX_HEADG_MAXK; ++k) acc[k] = acc[k] / sum;
+      }
+#pragma unroll
+      for (int k = 0; k < RX_HEADG_MAXK; ++k)
+        if (k < K) logits[((size_t)n * K + k) * V + v] = acc[k];
+    }
+  }
+}
+
+// out = lrelu((y - mean) * rstd) AND out_ncdhw = head(out) (+ eval-mode activation) in one pass; `stats` = (mean, rstd) of y.
+// Same `out` bit for bit and the same logits to fp32 round-off as rx_instnorm_act_fwd followed by rx_head_fwd.  K <= 4, 64 % (C / 8) == 0.
+extern "C" int rx_instnorm_act_head_fwd(rx_dtype dt, const rx_act* y, const float* stats, const rx_act* out, float slope,
+                                        const float* head_w, const float* head_b, int k, float* out_ncdhw, int act, void* stream) {
+  int rc = check_vec_channels(y, dt, "rx_instnorm_act_head_fwd(y)");
+  if (rc) return rc;
+  if ((rc = check_vec_channels(out, dt, "rx_instnorm_act_head_fwd(out)"))) return rc;
+  if (!stats || !head_w || !head_b || !out_ncdhw || !same_geom(y, out)) RX_FAIL(RX_EINVAL, "rx_instnorm_act_head_fwd: bad arguments");
+  if (dt == RX_F32 || k < 1 || k > RX_HEADG_MAXK || 64 % (y->c / 8) != 0)
+    RX_FAIL(RX_EUNSUPPORTED, "rx_instnorm_act_head_fwd: 16-bit types, K <= %d, C / 8 dividing 64", RX_HEADG_MAXK);
+  const long V = rx_act_voxels(y);
+  hipStream_t st = (hipStream_t)stream;
+  RX_DISPATCH_DTYPE(dt, T, {
+    constexpr int P = Elem<T>::PER16;
+    int CV = y->c / P;
+    int G = sweep_grid(V * CV, CV);
+    hipLaunchKernelGGL((in_act_head_fwd_kernel<T>), dim3(G, y->n), dim3(256), 0, st, (const T*)y->ptr, y->ld, V * y->ld, stats,
+                       (T*)out->ptr, out->ld, V * out->ld, (int)V, y->c, slope, head_w, head_b, k, out_ncdhw, act);
+  });
+  RX_CHECK_LAUNCH("rx_instnorm_act_head_fwd");
+  return RX_OK;
+}
+
 // ---- InstanceNorm backward of the layer that feeds a task head, with the head's data gradient formed on the fly ------
 // The gradient that reaches the last decoder conv block is rank K: g[v][c] = sum_k dlogit[k][v] * w_head[k][c] (K = 1 for a
 // segmentation head, 3 for normals).  rx_head_bwd used to write it as a full (N, V, C) tensor (268 MB at cfg2) that the two
 // passes of the InstanceNorm backward then read back twice.  Here both passes rebuild g from the fp32 logit gradient (4*K bytes
 // per voxel instead of 2*C) and the head's weights; rx_head_bwd is called with dx = NULL and only reduces dw / db.  g is
 // rounded to the storage type exactly where rx_head_bwd rounded it, so dy is bit-identical to the three-tensor path.
-#define RX_HEADG_MAXK 4
 template <typename T>
 struct InBwdHeadOp {
   ActView<T> y;

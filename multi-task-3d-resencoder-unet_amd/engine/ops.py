@@ -428,6 +428,12 @@ def head_bwd(dout_ncdhw, x, w, dx, dw, db, ws=None):
                              stream_ptr()), "rx_head_bwd")
 
 
+def instnorm_act_head_fwd(y, stats, out, w, b, out_ncdhw, act, slope=0.01):
+    """InstanceNorm apply + LeakyReLU + the task head's 1x1x1 conv (+ eval activation) in one pass over y"""
+    check(load().rx_instnorm_act_head_fwd(_code(y.dtype), byref(y.desc()), _ptr(stats), byref(out.desc()), float(slope), _ptr(w), _ptr(b),
+                                          w.shape[0], _ptr(out_ncdhw), int(act), stream_ptr()), "rx_instnorm_act_head_fwd")
+
+
 def instnorm_act_bwd_head(dout_ncdhw, w, y, stats, dy, slope=0.01, ws=None):
     """InstanceNorm + LeakyReLU backward of the layer under a task head; the head's data gradient dout x w is formed on the fly
     (head_bwd is then called with dx=None)"""

@@ -449,6 +449,21 @@ class Plan:
                     if "pool_to" not in src.a:
                         src.a["pool_to"] = rec.a
                         rec.a["fused"] = True
+            # the layer under a task head: InstanceNorm apply + LeakyReLU + the head's 1x1x1 conv in one pass (the activated
+            # output is written for the backward but not re-read by a separate head kernel)
+            if self.dtype != torch.float32 and os.environ.get("RX_FUSED_HEAD_FWD", "1") != "0":
+                for rec in tape:
+                    if rec.kind != "head" or rec.a["k"] > 4:
+                        continue
+                    prods = [r for r in tape if r.kind == "inact" and r.a["out"] is rec.a["x"]]
+                    if len(prods) != 1:
+                        continue
+                    pa = prods[0].a
+                    c = pa["out"].act.c
+                    if (pa["gate"] is None and pa["res"] is None and "pool_to" not in pa and not pa.get("norm_done")
+                            and pa["out"].act.voxels > 512 and c % 8 == 0 and 64 % (c // 8) == 0):
+                        pa["head_to"] = rec.a
+                        rec.a["fwd_fused"] = True
             for rec in tape:
                 a = rec.a
                 if rec.kind == "stem":
@@ -485,6 +500,13 @@ class Plan:
                 elif rec.kind == "inact":
                     def step(a=a):
                         res = a["res"].act if a["res"] is not None else None
+                        head = a.get("head_to")
+                        if head is not None:
+                            if not a.get("stats_done"):
+                                ops.instnorm_stats(a["y"].act, a["stats"], a["eps"])
+                            ops.instnorm_act_head_fwd(a["y"].act, a["stats"], a["out"].act, head["w"].view(head["k"], -1), head["b"],
+                                                      head["out"], head["act"] if P._apply_act else _l.RX_ACT_NONE, a["slope"])
+                            return
                         pool = a.get("pool_to")
                         if pool is not None:
                             if not a.get("stats_done"):
@@ -501,6 +523,9 @@ class Plan:
                 elif rec.kind == "copy":
                     f.append(lambda a=a: ops.avgpool_fwd(a["x"].act, a["y"].act, (1, 1, 1)))
                 elif rec.kind == "head":
+                    if a.get("fwd_fused"):          # computed by the InstanceNorm step of the layer below
+                        continue
+
                     def step(a=a):
                         w2 = a["w"].view(a["k"], -1)
                         ops.head_fwd(a["x"].act, w2, a["b"], a["out"], a["act"] if P._apply_act else _l.RX_ACT_NONE)

@@ -454,3 +454,27 @@ def test_instnorm_act_bwd_head_is_head_bwd_then_instnorm_bwd(ops, dtype, k, slop
     m2 = (gd * xh).mean(dim=(1, 2, 3), keepdim=True)
     ref = rstd * (gd - m1 - xh * m2)
     assert rel(dy2.t.float().cpu(), ref.float().cpu()) < (6e-3 if dtype == torch.bfloat16 else 8e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("k,act", [(1, 0), (3, 0), (1, 1), (3, 2)])
+def test_instnorm_act_head_fwd_is_the_two_calls(ops, dtype, k, act):
+    """rx_instnorm_act_head_fwd == rx_instnorm_act_fwd + rx_head_fwd: activated output bit for bit, fp32 logits to round-off (also with
+    the eval-mode sigmoid / softmax)"""
+    from mt3d_amd.engine import lib as _l
+    codes = {0: _l.RX_ACT_NONE, 1: _l.RX_ACT_SIGMOID, 2: _l.RX_ACT_SOFTMAX}
+    n, c, dims = 2, 32, (12, 20, 24)
+    y = to_act(ops, rnd((n, c, *dims), dtype, seed=31), dtype)
+    w = rnd((k, c), torch.float32, seed=32, scale=0.3).float().cuda().contiguous()
+    b = rnd((k,), torch.float32, seed=33).float().cuda().contiguous()
+    stats = torch.empty((n, c, 2), device="cuda")
+    ops.instnorm_stats(y, stats)
+    o1, o2 = ops.Act.empty(n, *dims, c, dtype), ops.Act.empty(n, *dims, c, dtype)
+    l1 = torch.empty((n, k, *dims), device="cuda")
+    l2 = torch.empty((n, k, *dims), device="cuda")
+    ops.instnorm_act_fwd(y, stats, o1, 0.01)
+    ops.head_fwd(o1, w, b, l1, codes[act])
+    ops.instnorm_act_head_fwd(y, stats, o2, w, b, l2, codes[act], 0.01)
+    torch.cuda.synchronize()
+    assert torch.equal(o1.t, o2.t)
+    assert torch.allclose(l1, l2, rtol=2e-6, atol=2e-6), (l1 - l2).abs().max()     # same products, fp32 sums differ in the last bit
