@@ -59,7 +59,11 @@ def pmc_traffic(kernel_label):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/*pmc_hbm_traffic.json: FETCH_SIZE x2 x1024 + WRITE_SIZE x1024, see scripts/pmc_traffic.py)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))
+    def _point(path):           # r01_<letters>_...: a, b, ..., z, aa, ab, ... in measurement order
+        parts = os.path.basename(path).split("_")
+        tag = parts[1] if len(parts) > 1 else ""
+        return (parts[0], len(tag), tag)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")), key=_point)
     if not files:
         return None
     try:
