@@ -10,9 +10,18 @@ The reference has no multi-GPU path; this is a new-build requiremen
   * xGMI is point-to-point (7 links x ~153 GB/s): few, large buckets (default 128 MiB) keep RCCL's
     ring/tree in its bandwidth regime; parameters without a gradient (the unused deep-supervision
     heads) are not engine inputs and therefore never enter a bucket;
-  * InstanceNorm statistics are per sample -> no statistic synchronisation exists.
+  * InstanceNorm statistics are per sample -> no statistic synchronisation exists;
+  * STREAMS: a bucket's gradients are produced on more than one HIP stream (conv / transposed-conv weight gradients on
+    the plan's side stream; SqueezeExcite fc gradients, head gradients and the zero fill of an unused task on the main
+    stream).  `ready()` notes the stream it is called on (the producer's), and the collective's stream waits for an event
+    recorded on EVERY stream that produced into the bucket -- not only on the stream of whoever closed it;
+  * gradient accumulation (`require_sync = False` / `no_sync()`, the equivalent of DDP.no_sync for the reference's
+    `gradient_accumulation > 1`, train.py:172,226-230): a micro-batch that does not step keeps its bucket LOCAL (carried,
+    summed on the device) and hands autograd no gradient; the stepping micro-batch adds the carry to its own bucket before
+    the one collective, so `.grad` ends up as mean_ranks(sum_microbatches g).
 Works unchanged with the gloo backend on CPU tensors (used by the world_size-2 tests).
 """
+import contextlib
 from typing import Dict, List, Optional
 
 import torch
@@ -20,11 +29,13 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("idxs", "offsets", "numel", "flat", "pending", "work")
+    __slots__ = ("idxs", "offsets", "numel", "flat", "pending", "work", "streams", "carry")
 
     def __init__(self):
         self.idxs, self.offsets, self.numel = [], {}, 0
         self.flat, self.pending, self.work = None, 0, None
+        self.streams = {}          # stream id -> torch.cuda.Stream of every producer of this bucket (this backward)
+        self.carry = None          # local sum of the un-synchronised micro-batches (gradient accumulation)
 
 
 class GradSync:
@@ -41,7 +52,24 @@ class GradSync:
         self._of: Dict[int, _Bucket] = {}
         self._params = None
         self._side = None
-        self.stats = dict(buckets=0, bytes=0)
+        self.require_sync = True        # False: accumulate locally, no collective (see no_sync)
+        self._syncing = True            # value of require_sync latched by begin() for the running backward
+        self.stats = dict(buckets=0, bytes=0, collectives=0)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """backward passes inside this context keep their gradients local (summed into a carry); the first backward
+        outside it reduces carry + its own gradients in one collective per bucket"""
+        old, self.require_sync = self.require_sync, False
+        try:
+            yield
+        finally:
+            self.require_sync = old
+
+    @property
+    def returns_grads(self):
+        """does the running backward hand gradients to autograd?  (a local micro-batch keeps them in the carry)"""
+        return self._syncing
 
     # ---- static layout per plan -----------------------------------------------------------------
     def _plan_layout(self, plan):
@@ -67,16 +95,18 @@ class GradSync:
         self._cur = self._plan_layout(plan)
         self._params = plan.params
         self._of = {}
+        self._syncing = bool(self.require_sync)
         dev = plan.params[0].device
         for b in self._cur:
             b.flat = torch.empty(b.numel, dtype=torch.float32, device=dev)
             b.pending = len(b.idxs)
             b.work = None
+            b.streams = {}
             for i in b.idxs:
                 self._of[i] = b
         if dev.type == "cuda" and self._side is None:
             self._side = torch.cuda.Stream(device=dev)
-        self.stats = dict(buckets=len(self._cur), bytes=sum(b.numel for b in self._cur) * 4)
+        self.stats = dict(buckets=len(self._cur), bytes=sum(b.numel for b in self._cur) * 4, collectives=0)
 
     def alloc(self, idx):
         b = self._of[idx]
@@ -85,30 +115,47 @@ class GradSync:
         return b.flat[o:o + p.numel()].view(p.shape)
 
     def ready(self, idx):
+        """called right after the LAST kernel writing gradient `idx` was enqueued, on the stream it was enqueued on"""
         b = self._of[idx]
+        if b.flat.is_cuda:
+            st = torch.cuda.current_stream()
+            b.streams[st.cuda_stream] = st
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
 
-    def _launch(self, b):
+    def _reduce(self, b):
+        """(on the collective's stream / the host for CPU tensors) carry + own gradients, then the collective"""
+        if b.carry is not None:
+            b.flat.add_(b.carry)
+            b.carry = None
+        if not self._syncing:
+            b.carry = b.flat            # stays local; the stepping micro-batch picks it up
+            return
         if self.world == 1:
             return
-        if b.flat.is_cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self._side.wait_event(ev)
-            with torch.cuda.stream(self._side):
-                if self.average and self._native_avg:
-                    b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-                else:
-                    if self.average:
-                        b.flat.div_(self.world)        # pre-scale: sum of (g / world) == mean, no overflow step
-                    b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            b.flat.record_stream(self._side)
+        self.stats["collectives"] += 1
+        if self.average and self._native_avg and b.flat.is_cuda:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         else:
             if self.average:
-                b.flat.div_(self.world)
+                b.flat.div_(self.world)        # pre-scale: sum of (g / world) == mean, no overflow step
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _launch(self, b):
+        if self.world == 1 and b.carry is None and self._syncing:
+            return
+        if b.flat.is_cuda:
+            # every stream that produced into this bucket: the kernels enqueued there so far include all of the bucket's
+            for st in b.streams.values():
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                self._reduce(b)
+            b.flat.record_stream(self._side)
+        else:
+            self._reduce(b)
 
     def finish(self):
         for b in self._cur or []:
@@ -119,6 +166,12 @@ class GradSync:
         if self._cur and self._cur[0].flat.is_cuda and self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         self._cur = None
+
+    def drop_carry(self):
+        """forget accumulated local gradients (e.g. `optimizer.zero_grad()` in the middle of an accumulation window)"""
+        for buckets in self._layout.values():
+            for b in buckets:
+                b.carry = None
 
 
 def broadcast_parameters(module, src=0, group=None):

@@ -923,9 +923,11 @@ class Plan:
             step()
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)     # every weight gradient is complete
+        grads = self._grads
         if self.grad_sync is not None:
             self.grad_sync.finish()
-        grads = self._grads
+            if not self.grad_sync.returns_grads:    # a local micro-batch of an accumulation window: the synchroniser carries
+                grads = [None] * len(self.params)   # the gradients until the stepping micro-batch (engine/ddp.py::no_sync)
         self._grads = []
         return grads
 

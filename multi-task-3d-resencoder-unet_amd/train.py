@@ -85,10 +85,23 @@ class BaseTrainer:
         n = len(dataset)
         idx = list(range(n))
         np.random.shuffle(idx)
+        if self.world > 1 and dist.is_initialized():
+            # ONE permutation for the whole job (rank 0's): per-rank shuffles would give every rank its own train / val
+            # partition -- overlapping training slices, one rank's validation samples in another rank's training set
+            perm = torch.tensor(idx, dtype=torch.int64)
+            if dist.get_backend() == "nccl":
+                perm = perm.cuda(self.local_rank)
+            dist.broadcast(perm, src=0)
+            idx = perm.cpu().tolist()
         split = int(np.floor(self.mgr.tr_val_split * n))
         tr, va = idx[:split], idx[split:] or idx[-1:]
-        if self.world > 1:                               # each rank trains on its own slice
-            tr = tr[self.rank::self.world]
+        if self.world > 1:
+            # each rank trains on its own slice; all slices have the SAME length (DistributedSampler drop_last semantics), so
+            # every rank runs the same number of backward passes / collectives and flushes on the same iterations
+            per_rank = len(tr) // self.world
+            if per_rank == 0:
+                raise ValueError(f"{len(tr)} training patches cannot be split over {self.world} ranks")
+            tr = tr[:per_rank * self.world][self.rank::self.world]
         workers = self.mgr.train_num_dataloader_workers
         train = DataLoader(dataset, batch_size=self.mgr.train_batch_size, sampler=SubsetRandomSampler(tr),
                            pin_memory=True, num_workers=workers)
@@ -111,7 +124,11 @@ class BaseTrainer:
     def train(self):
         if self.world > 1 and not dist.is_initialized():
             torch.cuda.set_device(self.local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            backend = os.environ.get("RX_DDP_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm; "gloo" for rehearsals on one GPU
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(backend)
         device = torch.device("cuda", self.local_rank if self.world > 1 else torch.cuda.current_device())
         model = self._build_model()
         optimizer = self._get_optimizer(model)
@@ -186,8 +203,11 @@ class BaseTrainer:
                 if i >= self.mgr.max_steps_per_epoch:
                     break
                 total, per, bsz = forward_loss(batch, True)
+                flush = (i + 1) % accum == 0 or (i + 1) == len(train_loader)
+                if sync is not None:        # DDP.no_sync equivalent: only the stepping micro-batch all-reduces
+                    sync.require_sync = flush
                 scaler.scale(total / accum).backward()
-                if (i + 1) % accum == 0 or (i + 1) == len(train_loader):
+                if flush:
                     if stepper is not None and not scaler.is_enabled():
                         torch.nn.utils.clip_grad_norm_(params, 3)
                         stepper.step()
@@ -196,13 +216,14 @@ class BaseTrainer:
                     scaler.update()
                     optimizer.zero_grad(set_to_none=True)
                 for k, v in per.items():
-                    running[k] += float(v)
-                steps += 1
+                    running[k] = running[k] + v         # device scalars: no host sync inside the epoch (the reference's
+                steps += 1                              # `.item()` per task and step, train.py:215-218, stalls the queue)
                 patches += bsz
             if stepper is not None:
                 stepper.synchronize()
             torch.cuda.synchronize(device)
             dt = time.perf_counter() - t0
+            running = {k: float(v) for k, v in running.items()}
             self.last_patches_per_sec = patches * self.world / max(dt, 1e-9)
             desc = " | ".join(f"{k}: {running[k] / max(steps, 1):.4f}" for k in running)
             self._log(f"[Train] Epoch {epoch + 1} => {desc} | {self.last_patches_per_sec:.2f} patches/s")
@@ -226,8 +247,9 @@ class BaseTrainer:
                         break
                     _, per, _ = forward_loss(batch, False)
                     for k, v in per.items():
-                        vrun[k] += float(v)
+                        vrun[k] = vrun[k] + v
                     vsteps += 1
+                vrun = {k: float(v) for k, v in vrun.items()}
                 for k in vrun:
                     self._log(f"Task '{k}', epoch {epoch + 1} avg val loss: {vrun[k] / max(vsteps, 1):.4f}")
             scheduler.step()

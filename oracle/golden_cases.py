@@ -17,6 +17,26 @@ TASKS_SOFTMAX2 = {
             "loss_kwargs": {"alpha": 0.5, "beta": 0.5}},
 }
 
+TASKS_SIGMOID_SHEET = {
+    "sheet": {"channels": 1, "activation": "sigmoid", "weight": 1, "loss_fn": "BCEDiceLoss",
+              "loss_kwargs": {"alpha": 0.5, "beta": 0.5}},
+}
+TASKS_SOFTMAX2_W1 = {
+    "seg": {"channels": 2, "activation": "softmax", "weight": 1, "loss_fn": "BCEDiceLoss",
+            "loss_kwargs": {"alpha": 0.5, "beta": 0.5}},
+}
+
+
+def _manual(**kw):
+    """manual topology (autoconfigure False); block names are Python LITERALS of this file (interned), which is what the
+    reference's `is` comparisons (encoder.py:72-79) need -- strings parsed from YAML never select these paths upstream"""
+    mc = {"basic_encoder_block": "BasicBlockD", "basic_decoder_block": "ConvBlock", "bottleneck_block": "BasicBlockD",
+          "features_per_stage": [32, 64, 128], "num_stages": 3, "n_blocks_per_stage": [1, 2, 2],
+          "kernel_sizes": [3, 3, 3], "n_conv_per_stage_decoder": [1, 1], "strides": [1, 2, 2]}
+    mc.update(kw)
+    return mc
+
+
 CASES = {
     # isotropic autoconfig, two task heads (cfg3-style, shrunk): 3 stages [32,64,128], blocks [1,3,4]
     "auto16_2head": dict(patch=(16, 16, 16), batch=2, in_channels=1, tasks=TASKS_2HEAD,
@@ -34,6 +54,53 @@ CASES = {
                                      "kernel_sizes": [3, 3, 3], "n_conv_per_stage_decoder": [1, 1],
                                      "strides": [1, 2, 2]},
                        seed=2, data_seed=11, train=True),
+    # ---- round 2: the non-default topologies the reference can build -------------------------------
+    # BottleneckD encoder (resblocks.py:135-259): 1x1x1 -> 3x3x3(stride) -> 1x1x1, projection skips
+    "bottleneck_enc": dict(patch=(16, 16, 16), batch=2, in_channels=1, tasks=TASKS_SIGMOID_SHEET, autoconfigure=False,
+                           model_config=_manual(basic_encoder_block="BottleneckBlockD", bottleneck_block="BottleneckBlockD",
+                                                bottleneck_channels=[32, 32, 64]),
+                           seed=11, data_seed=5, train=True,
+                           full_grads=("blocks.0.conv3.conv.weight", "stages.1.blocks.1.conv1.conv.weight",
+                                       "stages.0.blocks.0.conv2.conv.weight")),
+    # ResidualBlock decoder (decoder.py:68-100): StackedResidualBlocks on the concat, softmax 2-class head
+    "resdec_softmax": dict(patch=(16, 16, 16), batch=2, in_channels=1, tasks=TASKS_SOFTMAX2_W1, autoconfigure=False,
+                           model_config=_manual(basic_decoder_block="ResidualBlock"),
+                           seed=11, data_seed=5, train=True,
+                           full_grads=("seg.stages.1.blocks.0.skip.0.conv.weight", "seg.stages.1.blocks.0.conv2.conv.weight",
+                                       "seg.transpconvs.1.weight")),
+    # plain-conv encoder (encoder.py:122-130, selected by the "ResidualBlock" quirk) + nn.ReLU + two convs in decoder stage 0
+    "plain_relu_2conv": dict(patch=(16, 16, 16), batch=2, in_channels=2, tasks=TASKS_SIGMOID_SHEET, autoconfigure=False,
+                             model_config=_manual(basic_encoder_block="ResidualBlock", nonlin="nn.ReLU",
+                                                  n_conv_per_stage_decoder=[2, 1]),
+                             seed=11, data_seed=1, train=True,
+                             full_grads=("shared_encoder.stages.0.0.convs.0.conv.weight", "sheet.transpconvs.1.weight")),
+    # 2-D patch (op_dims == 2, build_network_from_config.py:188-205): Conv2d / InstanceNorm2d / AvgPool2d
+    "two_d": dict(patch=(32, 32), batch=2, in_channels=1, tasks=TASKS_SIGMOID_SHEET, autoconfigure=False,
+                  model_config=_manual(), seed=11, data_seed=5, train=True,
+                  full_grads=("stages.0.blocks.0.conv1.conv.weight", "sheet.transpconvs.1.weight",
+                              "sheet.stages.1.convs.0.conv.weight")),
+    # per-stage anisotropic kernels and strides given by hand
+    "aniso_kernels": dict(patch=(8, 16, 16), batch=2, in_channels=1, tasks=TASKS_SIGMOID_SHEET, autoconfigure=False,
+                          model_config=_manual(kernel_sizes=[[1, 3, 3], [3, 3, 3], [3, 3, 3]],
+                                               strides=[[1, 1, 1], [1, 2, 2], [2, 2, 2]]),
+                          seed=11, data_seed=1, train=True,
+                          full_grads=("stages.0.blocks.0.conv1.conv.weight", "sheet.transpconvs.1.weight",
+                                      "sheet.stages.1.convs.0.conv.weight")),
+}
+
+# Cases WITHOUT a reference fixture -- PARITY UNPINNED: SqueezeExcite / DropPath live in the un-vendored
+# dynamic_network_architectures package; the checker for these is the oracle's restatement of their published source.  Data
+# seeds curated like the golden ones (oracle/scan_seeds.py), so the live-oracle comparison can carry the 1e-3 bar too.
+UNPINNED_CASES = {
+    "squeeze_excite": dict(patch=(16, 16, 16), batch=2, in_channels=1, tasks=TASKS_SIGMOID_SHEET, autoconfigure=False,
+                           model_config=_manual(squeeze_excitation=True), seed=11, data_seed=5),
+    "squeeze_excite_bottleneck": dict(patch=(16, 16, 16), batch=2, in_channels=1, tasks=TASKS_SOFTMAX2_W1, autoconfigure=False,
+                                      model_config=_manual(basic_encoder_block="BottleneckBlockD",
+                                                           bottleneck_block="BottleneckBlockD",
+                                                           bottleneck_channels=[32, 32, 64], squeeze_excitation=True),
+                                      seed=11, data_seed=3),
+    "squeeze_excite_2d": dict(patch=(32, 32), batch=2, in_channels=1, tasks=TASKS_SIGMOID_SHEET, autoconfigure=False,
+                              model_config=_manual(squeeze_excitation=True), seed=11, data_seed=5),
 }
 
 # NOTE on data seeds: the network's backward is discontinuous in the LeakyReLU masks.  Gradients late in
@@ -41,7 +108,8 @@ CASES = {
 # fp32 evaluation orders moves a gradient tensor by 2e-3..2e-2 -- the reference's own fp32 CPU path differs from
 # its fp64 evaluation by that much on about half of all seeds (tests/test_oracle_golden.py::
 # test_fp32_gradients_are_mask_discontinuous).  The seeds below are ones where every mask has margin, so the
-# 1e-3 bar is meaningful.
+# 1e-3 bar is meaningful (`python oracle/scan_seeds.py` is the selection procedure: fp32 vs fp64 of the same path
+# at two thread counts, first seed below 3e-5).
 # parameters whose full gradient is stored in the fixture (small tensors); everything else is pinned
 # through (sum, l2) checksums
 FULL_GRAD_SUFFIXES = ("stem.convs.0.conv.weight", "seg_layers.1.weight", "seg_layers.1.bias",

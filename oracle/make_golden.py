@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY -- run in the build container (needs /root/reference):
 
-    python oracle/make_golden.py
+    python oracle/make_golden.py [case ...]
 
 Runs the REAL reference `NetworkFromConfig` (through oracle/ref_shim.py) and the REAL reference
 losses on seeded synthetic batches and writes `tests/golden/<case>.npz`:
@@ -37,7 +37,10 @@ def main():
     torch.set_num_threads(8)
     _, ref_losses = ref_shim.import_reference()
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]               # optional: regenerate just these cases
     for cname, c in CASES.items():
+        if only and cname not in only:
+            continue
         mgr = ref_shim.make_mgr(c["patch"], c["tasks"], c["in_channels"], c["batch"], c["autoconfigure"],
                                 c["model_config"])
         torch.manual_seed(c["seed"])
@@ -68,7 +71,7 @@ def main():
             else:
                 g = p.grad.double()
                 grad_ck.append([1.0, g.sum().item(), g.norm().item()])
-                if n.endswith(FULL_GRAD_SUFFIXES):
+                if n.endswith(FULL_GRAD_SUFFIXES + tuple(c.get("full_grads", ()))):
                     arrays[f"grad.{n}"] = p.grad.numpy()
         arrays["param_names"] = np.array(json.dumps(names))
         arrays["init_checksums"] = np.array(init_ck, dtype=np.float64)

@@ -50,6 +50,29 @@ def _worker(rank, world, port, q):
             expect = (sum(r + 1 + step for r in range(world)) / world) * (idx + 1)
             ok = ok and torch.allclose(g, torch.full_like(g, expect))
     ok = ok and outs[0][0].data_ptr() != outs[1][0].data_ptr()
+    # accumulation window (DDP.no_sync equivalent): two local micro-batches, then the stepping one -- ONE collective per bucket,
+    # result = mean over ranks of the window's sum
+    window = []
+    for mb, syncing in enumerate([False, False, True]):
+        sync.require_sync = syncing
+        sync.begin(plan)
+        ok = ok and sync.returns_grads == syncing
+        grads = {}
+        for idx in plan.grad_order:
+            g = sync.alloc(idx)
+            g.copy_(torch.full(plan.params[idx].shape, float(10 * mb + rank + 1)) * (idx + 1))
+            grads[idx] = g
+            sync.ready(idx)
+        sync.finish()
+        window.append((dict(sync.stats), grads))
+    ok = ok and window[0][0]["collectives"] == 0 and window[1][0]["collectives"] == 0
+    ok = ok and window[2][0]["collectives"] == window[2][0]["buckets"]
+    for idx, g in window[2][1].items():
+        expect = sum(sum(10 * mb + r + 1 for mb in range(3)) for r in range(world)) / world * (idx + 1)
+        ok = ok and torch.allclose(g, torch.full_like(g, expect))
+    with sync.no_sync():
+        ok = ok and sync.require_sync is False
+    ok = ok and sync.require_sync is True
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
@@ -65,3 +88,40 @@ def test_bucketed_allreduce_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _split_worker(rank, world, port, cfg_path, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.train import BaseTrainer
+    np.random.seed(1000 + rank)                     # every rank's own RNG state, as in a real launch
+    tr = BaseTrainer(cfg_path, verbose=False)
+    train, val = tr._configure_dataloaders(tr._configure_dataset())
+    q.put((rank, sorted(train.sampler.indices), sorted(val.sampler.indices), len(train)))
+    dist.destroy_process_group()
+
+
+def test_trainer_data_split_is_one_partition_for_all_ranks(tmp_path):
+    """per-rank unseeded shuffles gave every rank its own train/val partition and unequal loader lengths
+    (a hang in all_reduce when one rank runs an extra backward)."""
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "tasks", "synthetic_sheet.yaml")))
+    cfg["dataset_config"]["synthetic_length"] = 19          # 17 training patches -> 8 per rank, one dropped
+    p = tmp_path / "cfg.yaml"
+    yaml.safe_dump(cfg, open(p, "w"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, str(p), q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for pr in procs:
+        pr.join(timeout=60)
+    (_, tr0, va0, n0), (_, tr1, va1, n1) = res
+    assert va0 == va1 and len(va0) == 2
+    assert len(tr0) == len(tr1) == 8 and n0 == n1
+    assert not set(tr0) & set(tr1) and not (set(tr0) | set(tr1)) & set(va0)

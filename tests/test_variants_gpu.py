@@ -10,34 +10,17 @@ pytestmark = pytest.mark.gpu
 import resenc_oracle as oracle
 from helpers import rel_l2
 
-SEG = {"seg": {"channels": 2, "activation": "softmax", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
+from golden_cases import CASES, UNPINNED_CASES, _manual as manual
+
 ONE = {"sheet": {"channels": 1, "activation": "sigmoid", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
 
-
-def manual(**kw):
-    mc = {"basic_encoder_block": "BasicBlockD", "basic_decoder_block": "ConvBlock", "bottleneck_block": "BasicBlockD",
-          "features_per_stage": [32, 64, 128], "num_stages": 3, "n_blocks_per_stage": [1, 2, 2],
-          "kernel_sizes": [3, 3, 3], "n_conv_per_stage_decoder": [1, 1], "strides": [1, 2, 2]}
-    mc.update(kw)
-    return mc
-
-
-VARIANTS = {
-    "bottleneck_encoder": dict(patch=(16, 16, 16), cin=1, tasks=ONE, mc=manual(
-        basic_encoder_block="BottleneckBlockD", bottleneck_block="BottleneckBlockD", bottleneck_channels=[32, 32, 64])),
-    "residual_decoder": dict(patch=(16, 16, 16), cin=1, tasks=SEG, mc=manual(basic_decoder_block="ResidualBlock")),
-    "plain_encoder_relu": dict(patch=(16, 16, 16), cin=2, tasks=ONE, mc=manual(
-        basic_encoder_block="ResidualBlock", nonlin="nn.ReLU", n_conv_per_stage_decoder=[2, 1])),
-    "two_d": dict(patch=(32, 32), cin=1, tasks=ONE, mc=manual(kernel_sizes=[3, 3, 3])),
-    # PARITY UNPINNED (third-party SqueezeExcite: checked against the oracle's restatement of its published source)
-    "squeeze_excite": dict(patch=(16, 16, 16), cin=1, tasks=ONE, mc=manual(squeeze_excitation=True)),
-    "squeeze_excite_bottleneck": dict(patch=(16, 16, 16), cin=1, tasks=SEG, mc=manual(
-        basic_encoder_block="BottleneckBlockD", bottleneck_block="BottleneckBlockD", bottleneck_channels=[32, 32, 64],
-        squeeze_excitation=True)),
-    "squeeze_excite_2d": dict(patch=(32, 32), cin=1, tasks=ONE, mc=manual(squeeze_excitation=True)),
-    "aniso_kernels": dict(patch=(8, 16, 16), cin=1, tasks=ONE, mc=manual(
-        kernel_sizes=[[1, 3, 3], [3, 3, 3], [3, 3, 3]], strides=[[1, 1, 1], [1, 2, 2], [2, 2, 2]])),
-}
+# every variant is a curated case (oracle/golden_cases.py): seeds chosen with LeakyReLU/ReLU mask margin by oracle/scan_seeds.py,
+# so the live-oracle gradient comparison carries the north-star 1e-3 bar.  The first five are ALSO golden cases: the oracle is
+# pinned bit-for-bit to the real reference on them (tests/test_oracle_vs_reference.py, tests/golden/<name>.npz) and
+# tests/test_network_gpu.py::test_fp32_matches_reference_golden replays the fixtures on the engine.  The squeeze_excite* ones
+# are PARITY UNPINNED (third-party SqueezeExcite: checked against the oracle's restatement of its published source).
+VARIANTS = {k: CASES[k] for k in ("bottleneck_enc", "resdec_softmax", "plain_relu_2conv", "two_d", "aniso_kernels")}
+VARIANTS.update(UNPINNED_CASES)
 
 
 @pytest.fixture(scope="module")
@@ -47,14 +30,14 @@ def NetworkFromConfig():
     return N
 
 
-def _run(NetworkFromConfig, patch, cin, tasks, mc, autoconf=False, batch=2, seed=11, dtype=torch.float32):
+def _run(NetworkFromConfig, patch, cin, tasks, mc, autoconf=False, batch=2, seed=11, dtype=torch.float32, data_seed=5):
     mgr = oracle.make_mgr(patch, tasks, cin, batch, autoconf, mc)
     torch.manual_seed(seed)
     ref = oracle.NetworkFromConfig(mgr)
     torch.manual_seed(seed)
     net = NetworkFromConfig(mgr).cuda()
     assert list(ref.state_dict().keys()) == list(net.state_dict().keys())
-    x, t = oracle.synthetic_batch(batch, cin, patch, tasks, 5)
+    x, t = oracle.synthetic_batch(batch, cin, patch, tasks, data_seed)
     net.compute_dtype = dtype
     o_r, o_n = ref(x), net(x.cuda())
     l_r = oracle.train_loss(o_r, t, tasks)
@@ -67,7 +50,8 @@ def _run(NetworkFromConfig, patch, cin, tasks, mc, autoconf=False, batch=2, seed
 @pytest.mark.parametrize("name", list(VARIANTS))
 def test_variant_fp32_matches_oracle(NetworkFromConfig, name):
     v = VARIANTS[name]
-    ref, net, o_r, o_n, l_r, l_n = _run(NetworkFromConfig, v["patch"], v["cin"], v["tasks"], v["mc"])
+    ref, net, o_r, o_n, l_r, l_n = _run(NetworkFromConfig, v["patch"], v["in_channels"], v["tasks"], v["model_config"],
+                                        batch=v["batch"], seed=v["seed"], data_seed=v["data_seed"])
     for k in o_r:
         assert o_n[k].shape == o_r[k].shape
         assert rel_l2(o_n[k].cpu(), o_r[k].detach()) < 2e-4, (name, k)
@@ -76,10 +60,9 @@ def test_variant_fp32_matches_oracle(NetworkFromConfig, name):
     for n in pr:
         assert (pr[n].grad is None) == (pn[n].grad is None), n
         if pr[n].grad is not None and pr[n].grad.norm() > 1e-6:
-            # un-curated seeds: allow for single LeakyReLU/ReLU mask flips (see test_oracle_golden.py)
-            assert rel_l2(pn[n].grad.cpu(), pr[n].grad) < 3e-2, (name, n)
+            assert rel_l2(pn[n].grad.cpu(), pr[n].grad) < 1e-3, (name, n, rel_l2(pn[n].grad.cpu(), pr[n].grad))
     ref.eval(); net.eval()
-    x, _ = oracle.synthetic_batch(2, v["cin"], v["patch"], v["tasks"], 5)
+    x, _ = oracle.synthetic_batch(v["batch"], v["in_channels"], v["patch"], v["tasks"], v["data_seed"])
     with torch.no_grad():
         e_r, e_n = ref(x), net(x.cuda())
     for k in e_r:
