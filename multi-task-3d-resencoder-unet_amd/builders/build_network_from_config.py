@@ -195,12 +195,12 @@ class NetworkFromConfig(nn.Module):
         self._plans = {}
         return super()._apply(fn, *a, **k)
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x):
-        if not x.is_cuda:
-            raise _l.RxError("NetworkFromConfig runs only on an MI355X (gfx950) HIP device: got a CPU tensor and "
-                             "there is no CPU/PyTorch fallback (oracle/ holds the CPU checker used by the tests)")
-        if x.dim() != self.op_dims + 2 or x.shape[1] != self.in_channels:
-            raise ValueError(f"expected input (B, {self.in_channels}, *{self.op_dims} spatial dims), got {tuple(x.shape)}")
+        """`torch.compile(model)` (reference train.py:133) survives: the forward is one opaque engine call (ctypes launches
+        on raw pointers, nothing a tracer could lower), so dynamo is told to run it as it is; the compiled wrapper still
+        trains and its `state_dict()` carries the reference's `_orig_mod.` keys (train.py:250)."""
+        self._check_input(x)
         dtype = self._resolve_dtype()
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         plan = self.plan_for(x.shape, dtype, x.device, needs_grad)
@@ -215,3 +215,22 @@ class NetworkFromConfig(nn.Module):
             return outs
         outs = plan.run_forward(x, apply_act=not self.training)
         return {n: outs[n].clone() for n in names}
+
+    def _check_input(self, x):
+        if not x.is_cuda:
+            raise _l.RxError("NetworkFromConfig runs only on an MI355X (gfx950) HIP device: got a CPU tensor and "
+                             "there is no CPU/PyTorch fallback (oracle/ holds the CPU checker used by the tests)")
+        if x.dim() != self.op_dims + 2 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected input (B, {self.in_channels}, *{self.op_dims} spatial dims), got {tuple(x.shape)}")
+
+    @torch.compiler.disable(recursive=True)
+    def forward_logits(self, x):
+        """inference-only forward that returns RAW logits in whatever mode the module is in (`forward` applies the task
+        activation in eval mode, build_network_from_config.py:320-323).  For callers that activate themselves -- the
+        reference's inference.py:121-133 does, after `model.eval()` (:112) -- without switching the module to train mode,
+        which would also switch stochastic depth on."""
+        self._check_input(x)
+        with torch.no_grad():
+            plan = self.plan_for(x.shape, self._resolve_dtype(), x.device, False)
+            outs = plan.run_forward(x, apply_act=False)
+            return {n: outs[n].clone() for n in self.task_decoders.keys()}

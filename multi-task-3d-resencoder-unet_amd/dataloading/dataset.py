@@ -7,6 +7,7 @@ constructor, valid-patch search, cache file, dtype scaling and item layout as th
 albumentations / volumentations (absent) and are NOT applied, remote (http) stores are refused (no network)."""
 import json
 import os
+import warnings
 from pathlib import Path
 
 import numpy as np
@@ -89,6 +90,7 @@ def _ball(radius):
 
 class ZarrSegmentationDataset3D(Dataset):
     """dataloading/dataset.py:18-222 without the augmentation stack (see the module docstring)."""
+    _warned = False
 
     def __init__(self, mgr):
         self.mgr = mgr
@@ -101,6 +103,15 @@ class ZarrSegmentationDataset3D(Dataset):
         self.dilate_label = mgr.dilate_label
         self.use_cache = mgr.use_cache
         self.cache_folder = mgr.cache_folder
+        # the reference's recipe augments every item (dataset.py:171-205: brightness / noise / blur OneOf groups,
+        # CoarseDropout3D) with albumentations / volumentations, which are not installed here: say so ONCE per process instead
+        # of silently training a different recipe; `dataset_config.augment: false` acknowledges it
+        if bool(getattr(mgr, "dataset_config", {}).get("augment", True)) and not ZarrSegmentationDataset3D._warned:
+            ZarrSegmentationDataset3D._warned = True
+            warnings.warn("ZarrSegmentationDataset3D: the reference's augmentation stack (dataloading/dataset.py:171-205) needs "
+                          "albumentations / volumentations, which are absent -- patches are fed UN-AUGMENTED, so a real-data "
+                          "run is not the reference's training recipe.  Set dataset_config.augment: false to acknowledge.",
+                          RuntimeWarning, stacklevel=2)
         self.volumes = []
         for vol_idx, info in enumerate(self.volume_paths):
             vd = {"input_path": info["input"], "targets_path": {}, "ref_label_key": info.get("ref_label", "sheet")}

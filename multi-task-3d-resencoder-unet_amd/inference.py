@@ -7,8 +7,9 @@ patch positions helpers.py:200-216.  The reference streams every patch through z
 per patch) and is broken at HEAD against its own ConfigManager; here the volume, the sum and the count
 accumulators live in HBM for the whole run and only the finished arrays come back.
 
-The forward passes are the HIP engine's eval-mode plans (logits only -- the activation is applied HERE exactly as
-inference.py:121-133 does it from the target's `activation` key, never twice), so a CPU tensor is an error as everywhere
+The forward passes are the HIP engine's inference plans with the module in eval mode (inference.py:112; stochastic depth off),
+asked for raw logits (`NetworkFromConfig.forward_logits`) -- the activation is applied HERE exactly as
+inference.py:121-133 does it from the target's `activation` key, never twice, so a CPU tensor is an error as everywhere
 else in this package.  Accumulation / blending are a handful of torch slice ops on device tensors: plumbing, not kernels.
 """
 from typing import Dict, Optional, Sequence, Tuple
@@ -44,7 +45,7 @@ def all_positions(shape: Sequence[int], patch: Sequence[int], overlap: float):
 class SlidingWindowInferer:
     """`SlidingWindowInferer(model, targets, patch_size, batch_size, overlap)(volume)` -> dict of arrays.
 
-    model    : NetworkFromConfig (HIP engine); put into eval mode here.
+    model    : NetworkFromConfig (HIP engine); run in eval mode (restored afterwards).
     targets  : mapping name -> {"channels": c, "activation": "sigmoid" | "softmax" | "none"}  (inference.py:121-133);
                defaults to the model's own task table.
     volume   : (C, Z, Y, X) or (Z, Y, X) float array / tensor, host or device.
@@ -85,7 +86,8 @@ class SlidingWindowInferer:
         sums = {n: torch.zeros((int(t["channels"]), Z, Y, X), dtype=torch.float32, device=self.device) for n, t in self.targets.items()}
         count = torch.zeros((Z, Y, X), dtype=torch.float32, device=self.device)
         was_training = self.model.training
-        self.model.train()          # logits out of the engine; the activation is applied below, once (inference.py:121-133)
+        self.model.eval()           # inference.py:112 (DropPath off); logits come from `forward_logits`, the activation is
+                                    # applied below, once (inference.py:121-133)
         prev_dtype = getattr(self.model, "compute_dtype", None)
         if self.compute_dtype is not None:
             self.model.compute_dtype = self.compute_dtype
@@ -95,7 +97,7 @@ class SlidingWindowInferer:
                 while len(chunk) < self.batch_size and i > 0:      # keep ONE plan shape: pad the last batch with a repeat
                     chunk = chunk + [chunk[-1]]
                 patches = torch.stack([vol[:, z:z + pz, y:y + py, x:x + px] for z, y, x in chunk]).contiguous()
-                raw = self.model(patches)
+                raw = self.model.forward_logits(patches)
                 valid = min(self.batch_size, len(pos) - i)
                 for name, t in self.targets.items():
                     pred = self._activate(raw[name].float(), t.get("activation", "none"))

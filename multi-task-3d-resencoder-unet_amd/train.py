@@ -5,8 +5,10 @@ Same constructor and overridable hooks (`_build_model`, `_configure_dataset`, `_
 accumulation flush condition incl. the reference's `len(train_dataloader)` quirk, `clip_grad_norm_(…, 3)`,
 per-epoch checkpoint dict {'model','optimizer','scheduler','epoch'} pruned to 10, validation each epoch,
 CosineAnnealingLR stepped per epoch, final `<model_name>_final.pth`).  Differences, all documented in DESIGN.md:
-  * no `torch.compile` (the engine is one opaque autograd boundary) -> checkpoint keys carry no `_orig_mod.`;
-    a reference checkpoint with that prefix is accepted on load;
+  * `model = torch.compile(model)` is kept (train.py:133) so that checkpoints carry the reference's `_orig_mod.` keys
+    (train.py:250); the engine's forward is marked `torch.compiler.disable` -- it is one opaque autograd boundary over
+    ctypes launches, there is nothing for a tracer to lower.  `tr_config.compile: false` skips the wrapper; checkpoints
+    with or without the prefix are accepted on load;
   * `tr_config.amp_dtype` ("bf16" default | "fp16" | "fp32") picks the autocast dtype; a GradScaler is only
     enabled for fp16;
   * launched under `torch.distributed.run` it becomes data parallel (RCCL all-reduce overlapped with backward,
@@ -137,6 +139,9 @@ class BaseTrainer:
         scheduler = self._get_scheduler(optimizer)
         scaler = self._get_scaler()
         model = model.to(device)
+        engine_model = model                     # the NetworkFromConfig itself (plans, streamed step), whatever wraps it
+        if bool(self.mgr.tr_configs.get("compile", True)):
+            model = torch.compile(model)         # reference train.py:133; state_dict keys gain `_orig_mod.` (train.py:250)
         amp_dtype = _AMP[self._amp_name()]
         sync = None
         if self.world > 1:
@@ -154,7 +159,7 @@ class BaseTrainer:
         if self.mgr.checkpoint_path is not None and Path(self.mgr.checkpoint_path).exists():
             self._log(f"Loading checkpoint from {self.mgr.checkpoint_path}")
             ck = torch.load(self.mgr.checkpoint_path, map_location=device, weights_only=True)
-            model.load_state_dict(self._strip_compile_prefix(ck["model"]))
+            engine_model.load_state_dict(self._strip_compile_prefix(ck["model"]))
             if not self.mgr.load_weights_only:
                 optimizer.load_state_dict(ck["optimizer"])
                 scheduler.load_state_dict(ck["scheduler"])
@@ -173,8 +178,8 @@ class BaseTrainer:
         params = [p for p in model.parameters()]
         # opt-in (RX_STREAMED_STEP=1): optimizer update + weight re-pack on the engine's side stream, overlapped with the
         # next forward (falls back to a plain optimizer.step() for anything but a fused Adam/AdamW; never with a GradScaler)
-        stepper = (StreamedOptimizerStep(optimizer, model)
-                   if isinstance(model, NetworkFromConfig) and os.environ.get("RX_STREAMED_STEP", "0") == "1" else None)
+        stepper = (StreamedOptimizerStep(optimizer, engine_model)
+                   if isinstance(engine_model, NetworkFromConfig) and os.environ.get("RX_STREAMED_STEP", "0") == "1" else None)
 
         def forward_loss(batch, train_mode):
             x = batch["image"].to(device, dtype=torch.float32, non_blocking=True)
@@ -182,7 +187,7 @@ class BaseTrainer:
             with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
                 out = model(x)
                 if sync is not None:
-                    for plan in model._plans.values():
+                    for plan in getattr(engine_model, "_plans", {}).values():
                         plan.grad_sync = sync
                 total, per = 0.0, {}
                 for name, gt in targets.items():

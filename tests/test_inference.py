@@ -93,3 +93,44 @@ def test_pipeline_matches_oracle_on_the_device():
         d = np.abs(got[name + "_final"].astype(np.int64) - final[name].astype(np.int64)).max()
         assert d <= 1, (name, d)
     assert got["sheet_final"].dtype == np.uint8 and got["normals_final"].dtype == np.uint16
+
+
+@pytest.mark.gpu
+def test_inference_with_stochastic_depth_is_deterministic_and_eval_mode():
+    """the inferer used to put the module into train mode to get raw logits, which also switched DropPath on
+    (random residual branches dropped and rescaled at inference).  With `stochastic_depth_p > 0` two runs must agree
+    bit for bit, equal the oracle's EVAL-mode network, and leave the module's mode untouched.  (DropPath / SqueezeExcite:
+    parity unpinned -- third-party classes, the checker is the oracle's restatement.)"""
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
+    from golden_cases import _manual
+    inf = _product()
+    tasks = {"sheet": {"channels": 1, "activation": "sigmoid"}}
+    mc = _manual(squeeze_excitation=True, stochastic_depth_p=0.5)
+    mgr = oracle.make_mgr((16, 16, 16), tasks, 1, 2, False, mc)
+    torch.manual_seed(3)
+    ref_net = oracle.NetworkFromConfig(mgr).eval()
+    torch.manual_seed(3)
+    net = NetworkFromConfig(mgr).cuda().train()
+    g = torch.Generator().manual_seed(6)
+    vol = torch.rand((1, 16, 24, 32), generator=g)
+    runner = inf.SlidingWindowInferer(net, tasks, (16, 16, 16), batch_size=2, overlap=0.5, compute_dtype=torch.float32)
+    a = runner(vol)
+    assert net.training                       # mode restored
+    b = runner(vol)
+    assert np.array_equal(a["sheet"], b["sheet"])
+    pos = inf.all_positions(vol.shape[1:], (16, 16, 16), 0.5)
+
+    def predict(patches):
+        with torch.no_grad():
+            out = ref_net(torch.from_numpy(patches))          # eval mode: DropPath is the identity, sigmoid applied by the net
+        return {k: torch.logit(v.double().clamp(1e-12, 1 - 1e-12)).float().numpy() for k, v in out.items()}
+    blended, _ = ioracle.sliding_window(vol.numpy(), predict, tasks, (16, 16, 16), 2, pos)
+    assert np.abs(a["sheet"] - blended["sheet"]).max() < 2e-4
+    # forward_logits == train-mode logits of a net without stochastic depth, whatever the mode
+    x = torch.rand((2, 1, 16, 16, 16), generator=g).cuda()
+    net.eval()
+    l1 = net.forward_logits(x)["sheet"]
+    with torch.no_grad():
+        act = net(x)["sheet"]
+    assert torch.allclose(torch.sigmoid(l1), act, atol=1e-6)

@@ -138,10 +138,13 @@ def test_fp32_live_oracle_32cube_two_steps(NetworkFromConfig):
                 assert pn[n].grad is None
                 continue
             if pr[n].grad.norm() > 1e-6:
-                # live, un-curated seeds: a single LeakyReLU mask flip costs up to ~2e-2 on a tensor (see
-                # tests/test_oracle_golden.py::test_fp32_gradients_are_mask_discontinuous); the 1e-3 bar is
-                # carried by the golden-fixture tests above, whose seeds have mask margin
-                assert rel_l2(pn[n].grad.cpu(), pr[n].grad) < 3e-2, (step, n)
+                # step 0: data seed 99 has LeakyReLU mask margin at the initial weights (the oracle's fp32 gradients sit 8.6e-6
+                # from its own fp64 evaluation, oracle/scan_seeds.py procedure) -> the north-star 1e-3 bar.  Step 1 runs on
+                # the UPDATED weights, where no seed of 30 keeps every mask clear of zero in a net this deep (the oracle's
+                # own fp32-vs-fp64 distance is 2.5e-3..2.9e-2 there, tests/test_oracle_golden.py::
+                # test_fp32_gradients_are_mask_discontinuous): its job is the logits check above (new weights are seen)
+                tol = 1e-3 if step == 0 else 3e-2
+                assert rel_l2(pn[n].grad.cpu(), pr[n].grad) < tol, (step, n, rel_l2(pn[n].grad.cpu(), pr[n].grad))
         with torch.no_grad():
             for n in pr:
                 if pr[n].grad is not None:
@@ -386,3 +389,43 @@ def test_streamed_engine_adamw_is_bit_identical(NetworkFromConfig):
             assert torch.equal(a[k], b[k]), k
     for n in p_a:
         assert torch.equal(p_a[n], p_b[n]), n
+
+
+def test_torch_compile_wrapper_trains_and_keeps_reference_checkpoint_keys(NetworkFromConfig):
+    """reference train.py:133 wraps the model in `torch.compile` unconditionally and saves `_orig_mod.`-prefixed keys
+    (train.py:250).  The engine's forward is `torch.compiler.disable`d (nothing to trace: ctypes launches on raw pointers),
+    so the wrapper must run the same kernels: logits and gradients bit-identical to the bare module, training step works."""
+    net, c, _ = build(NetworkFromConfig, "manual_2in")
+    g = load_golden("manual_2in")
+    x = torch.from_numpy(g["x"]).cuda()
+    targets = {k[len("target."):]: torch.from_numpy(v).cuda() for k, v in g.items() if k.startswith("target.")}
+    net.train()
+    out = net(x)
+    oracle.train_loss(out, targets, c["tasks"]).backward()
+    bare = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    bare_logits = {k: v.detach().clone() for k, v in out.items()}
+    net.zero_grad(set_to_none=True)
+
+    cm = torch.compile(net)
+    keys = list(cm.state_dict().keys())
+    assert keys and all(k.startswith("_orig_mod.") for k in keys)
+    assert [k[len("_orig_mod."):] for k in keys] == list(net.state_dict().keys())
+    opt = torch.optim.AdamW(cm.parameters(), lr=1e-3, fused=True)
+    with torch.autocast("cuda", enabled=False):
+        out = cm(x)
+    for k in out:
+        assert torch.equal(out[k], bare_logits[k]), k
+    loss = oracle.train_loss(out, targets, c["tasks"])
+    loss.backward()
+    for n, p in net.named_parameters():
+        if n in bare:
+            assert torch.equal(p.grad, bare[n]), n
+    before = net.shared_encoder.stem.convs[0].conv.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, net.shared_encoder.stem.convs[0].conv.weight)
+    out2 = cm(x)                                        # the next forward sees the updated weights
+    assert not torch.equal(out2[next(iter(out2))], bare_logits[next(iter(out2))])
+    cm.eval()
+    with torch.no_grad():
+        ev = cm(x)
+    assert all(v.shape == bare_logits[k].shape for k, v in ev.items())

@@ -62,10 +62,29 @@ CONV_CASES = [
 ]
 
 
+# which kernel instantiation the library must dispatch (16-bit modes) for the cases whose comment names one: a dispatch change
+# that silently moved them back onto the generic gather kernels would otherwise keep this file green.
+# (fwd, bwd-data, bwd-weight) as reported by rx_last_conv_kernel(); None = not pinned.
+EXPECT_KERNELS = {
+    (256, 256, (4, 4, 4), (3, 3, 3), (1, 1, 1)): ("igemm_fat_kernel", "igemm_fat_kernel", "wgrad_halo_kernel"),
+    (512, 512, (4, 4, 4), (3, 3, 3), (1, 1, 1)): ("igemm_fat_kernel", "igemm_fat_kernel", "wgrad_halo_kernel"),
+    (512, 512, (3, 8, 8), (3, 3, 3), (1, 1, 1)): ("igemm_fat_kernel", "igemm_fat_kernel", "wgrad_halo_kernel"),
+    (32, 32, (30, 36, 64), (3, 3, 3), (1, 1, 1)): ("conv_halo32p_kernel", "conv_halo32p_kernel", "wgrad_halo16ws_kernel"),
+    (64, 64, (14, 32, 64), (3, 3, 3), (1, 1, 1)): ("conv_halo64ws_kernel", "conv_halo64ws_kernel", "wgrad_halo16ws_kernel"),
+    (128, 64, (32, 32, 64), (3, 3, 3), (2, 2, 2)): (None, "dgrad_s2p_kernel", None),
+    (128, 64, (24, 40, 72), (3, 3, 3), (2, 2, 2)): (None, "dgrad_s2p_kernel", None),
+}
+
+
+def last_kernel(ops):
+    return ops.load().rx_last_conv_kernel().decode()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3d_fwd_bwd(ops, dtype, case):
     ci, co, dims, k, s = case
+    seen = {}
     n = 2
     x = rnd((n, ci, *dims), dtype, 1)
     w = rnd((co, ci, *k), dtype, 2, scale=(ci * k[0] * k[1] * k[2]) ** -0.5)
@@ -83,6 +102,7 @@ def test_conv3d_fwd_bwd(ops, dtype, case):
     w_fwd, w_bwd = ops.pack_conv_weight(w.float().cuda(), dtype)
     ya = ops.Act.zeros(n, *odims, co, dtype)
     ops.conv3d_fwd(xa, w_fwd, b.float().cuda(), ya, k, s)
+    seen["fwd"] = last_kernel(ops)
     assert rel(ya.to_ncdhw(), y_ref.detach()) < TOL[dtype]
     # no bias
     ops.conv3d_fwd(xa, w_fwd, None, ya, k, s)
@@ -91,13 +111,18 @@ def test_conv3d_fwd_bwd(ops, dtype, case):
     gya = to_act(ops, gy, dtype)
     dxa = ops.Act.zeros(n, *dims, ci, dtype)
     ops.conv3d_bwd_data(gya, w_bwd, dxa, k, s, accumulate=False)
+    seen["dgrad"] = last_kernel(ops)
     assert rel(dxa.to_ncdhw(), xr.grad) < TOL[dtype]
     ops.conv3d_bwd_data(gya, w_bwd, dxa, k, s, accumulate=True)      # dx += ...
     assert rel(dxa.to_ncdhw(), 2 * xr.grad) < 2 * TOL[dtype]
 
     dw = torch.empty((co, ci, *k), dtype=torch.float32, device="cuda")
     ops.conv3d_bwd_weight(xa, gya, dw, k, s)
+    seen["wgrad"] = last_kernel(ops)
     assert rel(dw, wr.grad) < TOL[dtype]
+    if dtype != torch.float32 and case in EXPECT_KERNELS:
+        for which, want in zip(("fwd", "dgrad", "wgrad"), EXPECT_KERNELS[case]):
+            assert want is None or seen[which] == want, (case, which, seen)
 
 
 CONVT_CASES = [

@@ -138,7 +138,8 @@ def test_droppath_training_and_eval(NetworkFromConfig):
     for n in pr:
         assert (pr[n].grad is None) == (pn[n].grad is None), n
         if pr[n].grad is not None and pr[n].grad.norm() > 1e-6:
-            assert rel_l2(pn[n].grad.cpu(), pr[n].grad) < 3e-2, n
+            # (data seed 5 has mask margin for this net and these forced factors: oracle fp32 vs fp64 2.3e-6)
+            assert rel_l2(pn[n].grad.cpu(), pr[n].grad) < 1e-3, (n, rel_l2(pn[n].grad.cpu(), pr[n].grad))
     # the random draw itself: per-sample values in {0, 1/keep}
     net(x.cuda())
     plan = next(iter(net._plans.values()))

@@ -72,7 +72,16 @@ def test_dataset_items_and_valid_patches(tmp_path):
                           min_bbox_percent=0.9, dilate_label=False, use_cache=True, cache_folder=str(tmp_path / "cache"),
                           volume_paths=[{"input": paths["img"], "sheet": paths["sheet"], "normals": paths["normals"],
                                          "ref_label": "sheet"}])
-    ds = ZarrSegmentationDataset3D(mgr)
+    ZarrSegmentationDataset3D._warned = False
+    with pytest.warns(RuntimeWarning, match="UN-AUGMENTED"):        # the missing augmentation stack is announced, once
+        ds = ZarrSegmentationDataset3D(mgr)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ZarrSegmentationDataset3D(mgr)                              # second construction: silent
+        ZarrSegmentationDataset3D._warned = False
+        mgr.dataset_config = {"augment": False}                     # acknowledged in the config: silent
+        ZarrSegmentationDataset3D(mgr)
     nz = np.argwhere(lab > 0)
     bbox = tuple(int(v) for ax in range(3) for v in (nz[:, ax].min(), nz[:, ax].max()))
     assert find_label_bounding_box(zarr_lite.open(paths["sheet"]), (16, 16, 16)) == bbox
