@@ -52,6 +52,7 @@ def _worker(rank, world, port, cfg, q):
                for _ in range(nmb)]
         losses = {"sheet": BCEDiceLoss(alpha=0.5, beta=0.5), "normals": MaskedCosineLoss()}
         params = [p for p in net.parameters()]
+        names = [n for n, _ in net.named_parameters()]
 
         def backward(r, m):
             sl = slice(r * B, (r + 1) * B)
@@ -76,27 +77,15 @@ def _worker(rank, world, port, cfg, q):
                 backward(r, m)
                 local[(r, m)] = grab()
 
-        # ---- the data-parallel run of THIS rank
+        # ---- the data-parallel run of THIS rank, three times over (a race would not show on every pass)
         sync = GradSync(bucket_bytes=cfg["bucket_bytes"])
         for plan in net._plans.values():
             plan.grad_sync = sync
-        none_inside = True
-        for m in range(nmb):
-            sync.require_sync = (m == nmb - 1)
-            backward(rank, m)
-            if m < nmb - 1:
-                none_inside = none_inside and all(p.grad is None for p in params)
-        torch.cuda.synchronize()
-        got = grab()
-        stats = dict(sync.stats)
-
-        ok, worst, bad = True, 0.0, []
-        n_with_grad = 0
-        for i, g in enumerate(got):
+        expect = []
+        for i in range(len(params)):
             if local[(0, 0)][i] is None:
-                ok = ok and g is None
+                expect.append(None)
                 continue
-            n_with_grad += 1
             # the synchroniser's arithmetic, restated: (carry + own) / world on every rank, then the sum over ranks
             per_rank = []
             for r in range(world):
@@ -104,18 +93,47 @@ def _worker(rank, world, port, cfg, q):
                 for m in range(nmb):          # `flat.add_(carry)`: own gradients + what the window has carried so far
                     carry = local[(r, m)][i] if carry is None else local[(r, m)][i] + carry
                 per_rank.append(carry / world)
-            expect = per_rank[0]
+            e = per_rank[0]
             for r in range(1, world):
-                expect = expect + per_rank[r]
-            if g is None or not torch.equal(g, expect):
-                ok = False
-                d = float("inf") if g is None else (g - expect).abs().max().item()
-                worst = max(worst, d)
-                bad.append(i)
+                e = e + per_rank[r]
+            expect.append(e)
+        ok, none_inside, passes, stats = True, True, [], None
+        plan0 = next(iter(net._plans.values()))
+        pidx = {id(p): i for i, p in enumerate(params)}
+        bucket_of = {}
+        for bi, b in enumerate(sync._plan_layout(plan0)):      # which bucket each parameter travels in (failure diagnostics)
+            for j in b.idxs:
+                bucket_of[pidx[id(plan0.params[j])]] = bi
+        for rep in range(3):
+            for m in range(nmb):
+                sync.require_sync = (m == nmb - 1)
+                backward(rank, m)
+                if m < nmb - 1:
+                    none_inside = none_inside and all(p.grad is None for p in params)
+            torch.cuda.synchronize()
+            got = grab()
+            stats = dict(sync.stats)
+            bad = []
+            for i, (g, e) in enumerate(zip(got, expect)):
+                if e is None:
+                    ok = ok and g is None
+                elif g is None or not torch.equal(g, e):
+                    ok = False
+                    rel = float("inf") if g is None else ((g - e).norm() / e.norm().clamp(min=1e-30)).item()
+                    bad.append((names[i], rel, bucket_of.get(i, -1)))
+            passes.append(bad[:4] + bad[-4:] + [("n_bad", len(bad), sorted({b[2] for b in bad}))] if bad else [])
+        # is a plain single-process backward of this rank's half batch still what it was?  (tells a race inside the plan
+        # from one in the synchroniser)
+        for plan in net._plans.values():
+            plan.grad_sync = None
+        backward(rank, nmb - 1)
+        again = grab()
+        reproducible = all((a is None and b is None) or torch.equal(a, b) for a, b in zip(again, local[(rank, nmb - 1)]))
+        n_with_grad = sum(e is not None for e in expect)
         # the two ranks' half batches really differ (otherwise the test could not see a skipped collective)
         differs = any(a is not None and not torch.equal(a, b) for a, b in zip(local[(0, 0)], local[(1, 0)]))
-        q.put((rank, bool(ok), dict(stats=stats, worst=worst, bad=bad[:8], differs=differs, none_inside=none_inside,
-                                    n_with_grad=n_with_grad)))
+        q.put((rank, bool(ok), dict(stats=stats, passes=passes, differs=differs, none_inside=none_inside,
+                                    n_with_grad=n_with_grad, reproducible=reproducible)))
         dist.destroy_process_group()
     except Exception as e:      # noqa: BLE001 -- report instead of hanging the parent on q.get
         import traceback
@@ -150,8 +168,12 @@ def test_two_ranks_real_plan_equal_mean_of_half_batches(name, over):
     cfg = dict(BASE)
     cfg.update(over)
     res = _run(cfg)
+    import json
+    for rank, ok, info in res:
+        print(f"[{name}] rank {rank}: ok={ok} {json.dumps(info)}", flush=True)
     for rank, ok, info in res:
         assert "error" not in info, info
+        assert info["reproducible"], "a single-process backward of the same half batch changed: race inside the plan"
         assert info["differs"], "both ranks saw the same data"
         assert info["stats"]["buckets"] >= 2, info
         assert info["stats"]["collectives"] == info["stats"]["buckets"], info

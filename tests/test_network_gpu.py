@@ -121,7 +121,7 @@ def test_fp32_live_oracle_32cube_two_steps(NetworkFromConfig):
     ref = oracle.NetworkFromConfig(mgr)
     torch.manual_seed(5)
     net = NetworkFromConfig(mgr).cuda()
-    x, targets = oracle.synthetic_batch(1, 1, (32, 32, 32), tasks, 99)
+    x, targets = oracle.synthetic_batch(1, 1, (32, 32, 32), tasks, 107)
     for step in range(2):
         ref.train(); net.train()
         o_r = ref(x)
@@ -138,7 +138,7 @@ def test_fp32_live_oracle_32cube_two_steps(NetworkFromConfig):
                 assert pn[n].grad is None
                 continue
             if pr[n].grad.norm() > 1e-6:
-                # step 0: data seed 99 has LeakyReLU mask margin at the initial weights (the oracle's fp32 gradients sit 8.6e-6
+                # step 0: data seed 107 has LeakyReLU mask margin at the initial weights (the oracle's fp32 gradients sit 6e-6
                 # from its own fp64 evaluation, oracle/scan_seeds.py procedure) -> the north-star 1e-3 bar.  Step 1 runs on
                 # the UPDATED weights, where no seed of 30 keeps every mask clear of zero in a net this deep (the oracle's
                 # own fp32-vs-fp64 distance is 2.5e-3..2.9e-2 there, tests/test_oracle_golden.py::
