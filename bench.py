@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT]
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # dense, MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0                                                # HBM3E, MI355X_MICROARCH.md
 DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
 
 WORKLOADS = {
@@ -113,20 +114,23 @@ def host_threads():
     return max(1, min(n, 16))
 
 
-def cpu_baseline_worker(workload, threads):
-    """runs in a child process: the oracle (pure-PyTorch CPU restatement of the reference path, fp32) -- one
-    warm-up step at <=32^3, then ONE timed full train step of the workload at batch 1."""
+def cpu_baseline_worker(workload, threads, timed=2):
+    """runs in a child process: the oracle (pure-PyTorch CPU restatement of the reference path, fp32) -- ONE model and
+    optimizer, one untimed warm-up step and then TWO timed full train steps of the workload at batch 1 (BASELINE.md 3:
+    >= 1 warm-up + several timed; cfg2 costs ~7 s per step on 16 threads, so the sample stays within ~20-25 s)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import resenc_oracle as oracle
     w = WORKLOADS[workload]
     torch.set_num_threads(threads)
 
-    def one_step(patch, batch):
-        mgr = oracle.make_mgr(patch, w["tasks"], w["in_channels"], batch, w["autoconfigure"], w["model_config"])
-        torch.manual_seed(0)
-        net = oracle.NetworkFromConfig(mgr)
-        opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=0.0)
-        x, t = oracle.synthetic_batch(batch, w["in_channels"], patch, w["tasks"], 1234)
+    patch = w["patch"]
+    mgr = oracle.make_mgr(patch, w["tasks"], w["in_channels"], 1, w["autoconfigure"], w["model_config"])
+    torch.manual_seed(0)
+    net = oracle.NetworkFromConfig(mgr)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=0.0)
+    x, t = oracle.synthetic_batch(1, w["in_channels"], patch, w["tasks"], 1234)
+
+    def one_step():
         t0 = time.perf_counter()
         loss = oracle.train_loss(net(x), t, w["tasks"])
         loss.backward()
@@ -135,18 +139,20 @@ def cpu_baseline_worker(workload, threads):
         opt.zero_grad(set_to_none=True)
         return time.perf_counter() - t0
 
-    one_step(tuple(min(32, p) for p in w["patch"]), 1)
-    dt = one_step(w["patch"], 1)
+    warm = one_step()
+    times = [one_step() for _ in range(timed)]
+    dt = sum(times) / len(times)
     print(json.dumps(dict(value=1.0 / dt, unit="patches/s", cores=threads, kind="port",
-                          sample=f"1 full train step (fwd+loss+bwd+clip+AdamW) of {workload} at batch 1, patch "
-                                 f"{'x'.join(map(str, w['patch']))}, fp32, torch {torch.__version__} CPU, {dt:.1f} s")),
+                          sample=f"{timed} timed full train steps (fwd+loss+bwd+clip+AdamW) after 1 warm-up ({warm:.1f} s) of {workload} "
+                                 f"at batch 1, patch {'x'.join(map(str, patch))}, fp32, torch {torch.__version__} CPU: "
+                                 + ", ".join(f"{v:.1f} s" for v in times))),
           flush=True)
 
 
 def cpu_baseline(workload, timeout_s=300):
     import subprocess
     threads = host_threads()
-    print(f"[bench] timing the CPU oracle on {threads} threads (bounded: one step, <= {timeout_s} s) ...",
+    print(f"[bench] timing the CPU oracle on {threads} threads (bounded: 1 warm-up + 2 timed steps, <= {timeout_s} s) ...",
           file=sys.stderr, flush=True)
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload,
@@ -158,7 +164,51 @@ def cpu_baseline(workload, timeout_s=300):
         return dict(value=None, unit="patches/s", cores=threads, kind="port", sample=f"failed: {r.stderr[-300:]}")
     except subprocess.TimeoutExpired:
         return dict(value=None, unit="patches/s", cores=threads, kind="port",
-                    sample=f"one {workload} step at batch 1 did not finish within {timeout_s} s on {threads} threads")
+                    sample=f"3 {workload} steps at batch 1 did not finish within {timeout_s} s on {threads} threads")
+
+
+def through_trainer(workload, batch, dtype, warmup, steps):
+    """the same workload through the reference's plug-in surface: `BaseTrainer` (train.py:19-339 mirror) with its hooks, a
+    DataLoader over `SyntheticPatchDataset` (pinned memory, worker processes), torch.compile wrapper, autocast, the engine's AdamW
+    behind `_get_optimizer`.  Epoch 1 warms up (plan build), epoch 2 is reported (`BaseTrainer.last_patches_per_sec`: wall time of
+    the epoch's training loop between two device synchronisations, loss scalars accumulated on the device)."""
+    import tempfile
+    import yaml
+    from mt3d_amd.train import BaseTrainer
+    w = WORKLOADS[workload]
+    n_steps = max(warmup, 1) + steps
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = {
+            "tr_setup": {"model_name": f"bench_{workload}", "autoconfigure": w["autoconfigure"], "tr_val_split": 0.95,
+                         "ckpt_out_base": os.path.join(tmp, "ckpt"), "tensorboard_log_dir": os.path.join(tmp, "tb")},
+            "tr_config": {"optimizer": "AdamW", "initial_lr": 1e-3, "weight_decay": 0, "gradient_accumulation": 1,
+                          "num_dataloader_workers": min(8, host_threads()), "patch_size": list(w["patch"]), "batch_size": batch,
+                          "max_steps_per_epoch": n_steps, "max_val_steps_per_epoch": 1, "max_epoch": 2,
+                          "amp_dtype": dtype, "engine_optimizer": True},
+            "model_config": dict(w["model_config"]),
+            "dataset_config": {"synthetic": True, "synthetic_length": int(n_steps * batch / 0.95) + 2 * batch,
+                               "in_channels": w["in_channels"], "targets": w["tasks"]},
+            "inference_config": {},
+        }
+        path = os.path.join(tmp, "cfg.yaml")
+        with open(path, "w") as f:
+            yaml.safe_dump(cfg, f)
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            class Quiet(BaseTrainer):
+                rates = []
+
+                def _log(self, *a):
+                    if a and str(a[0]).startswith("[Train]"):
+                        self.rates.append(self.last_patches_per_sec)
+            tr = Quiet(path, verbose=False)
+            tr.train()
+        finally:
+            os.chdir(cwd)
+    return dict(value=Quiet.rates[-1], unit="patches/s", ms_per_step=batch / Quiet.rates[-1] * 1e3, steps=n_steps,
+                epochs_rates=Quiet.rates,
+                note="BaseTrainer.last_patches_per_sec of epoch 2 (DataLoader + pinned H2D + autocast + loss + clip + EngineAdamW)")
 
 
 def main():
@@ -171,6 +221,10 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the second timed loop that feeds every step from pinned host memory")
+    ap.add_argument("--through-trainer", action="store_true",
+                    help="also run the workload through the plug-in surface (BaseTrainer + SyntheticPatchDataset + DataLoader) "
+                         "and report its patches/s as `trainer`")
     ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)   # "gloo": rehearse N>1 on a 1-GPU box
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
@@ -273,6 +327,62 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # ---- the same K steps with the H2D copy of image + targets INSIDE the step (the reference's step starts at
+    # the `.to(device)` of a pinned DataLoader batch, train.py:195-201): two pinned host batches, two device batches, a copy
+    # stream that brings batch i+1 while step i computes.  Reported beside `value` (which keeps the batch resident in HBM),
+    # never instead of it.
+    h2d = None
+    if not args.no_h2d:
+        host = []
+        for j in range(2):
+            hx, ht = synthetic_batch(w, batch, 4321 + 2 * rank + j, "cpu")
+            host.append((hx.pin_memory(), {k: v.pin_memory() for k, v in ht.items()}))
+        dev = [(torch.empty_like(x), {k: torch.empty_like(v) for k, v in targets.items()}) for _ in range(2)]
+        copy_stream = torch.cuda.Stream(device=device)
+        ready = [torch.cuda.Event() for _ in range(2)]
+        consumed = [torch.cuda.Event() for _ in range(2)]
+
+        def prefetch(i):
+            b = i % 2
+            copy_stream.wait_event(consumed[b])                 # the step that last read device batch b is over
+            with torch.cuda.stream(copy_stream):
+                dev[b][0].copy_(host[b][0], non_blocking=True)
+                for k in targets:
+                    dev[b][1][k].copy_(host[b][1][k], non_blocking=True)
+                ready[b].record(copy_stream)
+
+        def fed_step(i):
+            nonlocal x, targets
+            b = i % 2
+            torch.cuda.current_stream().wait_event(ready[b])
+            prefetch(i + 1)
+            x, targets = dev[b]
+            loss = step()
+            consumed[b].record(torch.cuda.current_stream())
+            return loss
+
+        x0, t0_ = x, targets
+        for b in range(2):
+            consumed[b].record(torch.cuda.current_stream())
+        prefetch(0)
+        for i in range(2):
+            fed_step(i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for i in range(2, 2 + args.steps):
+            fed_step(i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dth = time.perf_counter() - th
+        x, targets = x0, t0_
+        nbytes = x.numel() * 4 + sum(v.numel() * 4 for v in targets.values())
+        h2d = dict(value=world * batch * args.steps / dth, unit="patches/s", ms_per_step=dth / args.steps * 1e3,
+                   h2d_bytes_per_step=nbytes,
+                   note="same loop, every step fed from pinned host memory (image + targets, double-buffered on a copy stream)")
+
     # Per-kernel durations for the roofline: HIP events around every conv launch, on the stream it is enqueued on, over
     # `prof_steps` further steps of the same loop right after the timed region (two event records per launch cost
     # ~4 % of a step: they stay out of `value`; with RX_GRAPHS=1 events cannot be inserted into the replayed graphs
@@ -329,6 +439,17 @@ def main():
                                 avg_us_per_launch=g["ms"] * 1e3 / max(g["launches"], 1),
                                 flops_per_launch=g["flops"] / max(g["launches"], 1),
                                 note=f"HIP events over {prof_steps} further steps of the same loop, right after the timed region")
+        hbm = None
+        if prof is not None and prof.hbm:
+            # HBM-bound launches: ALGORITHMIC bytes (each operand tensor once) / HIP-event time on their stream,
+            # in the overlapped step (contended with the other stream), as fraction of the 8 TB/s HBM3E peak
+            hbm = {}
+            for name, g in sorted(prof.hbm.items(), key=lambda kv: -kv[1]["ms"]):
+                gbps = g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0
+                hbm[name] = dict(ms_per_step=g["ms"] / prof_steps, launches_per_step=g["calls"] / prof_steps,
+                                 GB_per_step=g["bytes"] / prof_steps / 1e9, achieved_GBps=gbps, frac_of_peak=gbps / HBM_PEAK_GBPS)
+            hbm["_total"] = dict(ms_per_step=sum(v["ms_per_step"] for v in hbm.values()),
+                                 GB_per_step=sum(v["GB_per_step"] for v in hbm.values()), peak_GBps=HBM_PEAK_GBPS)
         line = {
             "metric": "train patches/sec (b,c,z,y,x) ResEncM 1x128^3", "value": value, "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -340,9 +461,12 @@ def main():
                        "global_batch": world * batch, "parallelism": f"dp{world}"},
             "final_loss": final_loss,
             "hip_graphs": bool(world == 1 and os.environ.get("RX_GRAPHS", "0") == "1"),
+            "launch_programs": bool(any(st.get("prog") is not None for plan in net._plans.values() for st in plan._pstate.values())),
             "roofline": roofline,
             "roofline_isolated": None,
             "kernels": kernels,
+            "hbm": hbm,
+            "with_h2d": h2d,
         }
         if iso is not None:
             gi = iso.collect()
@@ -350,11 +474,17 @@ def main():
                 isolated = {k: dict(avg_us_per_launch=v["ms"] * 1e3 / max(v["launches"], 1), tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12)
                             for k, v in gi.items() if v["ms"] > 0}
                 dom_i = roofline["kernel"] if roofline and roofline["kernel"] in isolated else max(isolated, key=lambda k: gi[k]["ms"])
+                if iso.hbm:
+                    line["hbm_isolated"] = {k: dict(achieved_GBps=v["bytes"] / (v["ms"] * 1e-3) / 1e9,
+                                                    frac_of_peak=v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS)
+                                            for k, v in iso.hbm.items() if v["ms"] > 0}
                 line["roofline_isolated"] = dict(kernel=dom_i, achieved=isolated[dom_i]["tflops"], peak=peak, unit="TFLOP/s",
                                                  frac=isolated[dom_i]["tflops"] / peak,
                                                  avg_us_per_launch=isolated[dom_i]["avg_us_per_launch"],
                                                  note="same kernels, weight-gradient stream overlap disabled (2 extra steps)",
                                                  all=isolated)
+        if args.through_trainer and world == 1:
+            line["trainer"] = through_trainer(args.workload, batch, args.dtype, args.warmup, args.steps)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
         else:

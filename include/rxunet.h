@@ -65,6 +65,10 @@ int rx_pack_conv_weight(rx_dtype dt, const float* w, int co, int ci, int taps, v
 /* ConvTranspose3d weight (Ci,Co,T) fp32 -> w_fwd [T][Co][Ci], w_bwd [T][Ci][Co] (tap order kept). */
 int rx_pack_convT_weight(rx_dtype dt, const float* w, int ci, int co, int taps, void* w_fwd, void* w_bwd,
                          void* stream);
+/* the same for `count` weights in ONE launch per 40 tensors (a train step re-packs every conv weight: 66 tensors at cfg2).
+ * kind[i] 0: Conv3d weight (A = Co, B = Ci), 1: ConvTranspose3d weight (A = Ci, B = Co); HOST arrays of device pointers. */
+int rx_pack_multi(rx_dtype dt, int count, const float* const* w, const int* kind, const int* A, const int* B,
+                  const int* taps, void* const* w_fwd, void* const* w_bwd, void* stream);
 
 /* ---- nn.Conv3d (simple_conv_blocks.py:43-51; kernel per axis in {1,3}, stride per axis in {1,2},
  *      padding (k-1)/2, dilation 1) ------------------------------------------------------- */
@@ -211,9 +215,6 @@ int rx_instnorm_act_bwd_head(rx_dtype dt, const float* dout_ncdhw, int k, const 
 size_t rx_channel_sum_workspace(const rx_act* x);
 int rx_channel_sum(rx_dtype dt, const rx_act* x, float* out, void* ws, size_t ws_bytes, void* stream);
 
-/* ---- fused train-step losses on NCDHW fp32 logits (training/losses/losses.py) ----------- */
-/* reserved for a later round; see DESIGN.md "next" */
-
 /* ---- task losses of the train step, single pass (reference training/losses/losses.py) ---------
  * logits / target / pred: (N, C, V) fp32, NCDHW-contiguous (V = Z*Y*X).  `loss` and `grad_loss` are DEVICE scalars
  * (no host synchronisation); `coef` carries the per-channel backward coefficients from fwd to bwd
@@ -253,6 +254,33 @@ int rx_grad_norm_clip(int count, const float* const* grad, const long* numel, fl
 int rx_adamw_flat_multi(int count, float* const* p, const float* const* grad, float* const* exp_avg,
                         float* const* exp_avg_sq, const long* numel, const float* clip, double lr, double beta1,
                         double beta2, double eps, double weight_decay, int step, void* stream);
+
+/* ---- launch programs: the launch list of a forward / backward pass, recorded once and replayed from C ------------------
+ * The reference's model call is ONE Python call (`model(x)`, train.py:204; `loss.backward()`, :224) behind which the
+ * framework issues its kernels natively.  A host-language loop over ~700 entry points per step costs ~8 ms of host time;
+ * a program issues the same calls from C.  Between rx_prog_begin and rx_prog_end every entry point above that takes a
+ * `stream` BOTH executes as usual AND appends itself -- arguments by value, rx_act / kernel / stride copied -- to the
+ * program (the recording pass is an ordinary step).  Streams are recorded by index into `streams` and substituted from
+ * the table given to rx_prog_run; device pointers are recorded as they are, so a program is valid as long as the buffers
+ * it was recorded on live at the same addresses.  rx_prog_run(first, last) replays commands [first, last) (last < 0: to
+ * the end) and returns the first non-zero status.  With `ms` != NULL (last - first floats) every command is bracketed by
+ * timing events on its stream and the streams are synchronised before returning (profiling replay; the only entry point
+ * that synchronises). */
+typedef struct rx_prog rx_prog;
+rx_prog* rx_prog_create(void);
+void rx_prog_destroy(rx_prog* p);
+int rx_prog_begin(rx_prog* p, void* const* streams, int n_streams);
+int rx_prog_end(rx_prog* p);
+int rx_prog_len(const rx_prog* p);
+const char* rx_prog_cmd_name(const rx_prog* p, int i);   /* entry point of command i */
+const char* rx_prog_cmd_kernel(const rx_prog* p, int i); /* kernel instantiation it dispatched at record time ("" if not a conv) */
+int rx_prog_cmd_stream(const rx_prog* p, int i);         /* index into the stream table */
+int rx_prog_run(rx_prog* p, int first, int last, void* const* streams, int n_streams, float* ms);
+/* numbered events for cross-stream ordering (recordable like everything else): rx_stream_wait makes `stream` wait for the
+ * work captured by the last rx_event_record(slot) issued before it. */
+int rx_event_new(void);
+int rx_event_record(int slot, void* stream);
+int rx_stream_wait(int slot, void* stream);
 
 #ifdef __cplusplus
 }

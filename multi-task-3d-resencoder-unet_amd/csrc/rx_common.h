@@ -3,9 +3,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/rxunet.h"
+
+// Host-side per-launch overhead: the dispatch code asks the environment for tuning knobs and (re)sets the dynamic-LDS limit of
+// the kernel it is about to launch on EVERY call (~700 launches per train step).  Both are answered from per-thread caches
+// after the first time (rx_prog.hip); the knobs are therefore read once per process, which is how they are used.
+const char* rx_getenv_cached(const char* name);
+hipError_t rx_func_attr_once(const void* fn, hipFuncAttribute attr, int value);
+#ifndef RX_NO_HOST_MACROS
+#define getenv(name) rx_getenv_cached(name)
+#define hipFuncSetAttribute(fn, attr, value) rx_func_attr_once((fn), (attr), (value))
+#endif
 
 #define RX_WAVE 64
 
@@ -20,6 +31,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#include "rx_prog.h"
 
 // ---- error plumbing (host) -----------------------------------------------------------------
 void rx_set_error(const char* fmt, ...);

@@ -24,7 +24,9 @@ void rx_set_error(const char* fmt, ...) {
 }
 extern "C" const char* rx_last_error(void) { return g_err; }
 static thread_local const char* g_last_kernel = "";
-void rx_note_kernel(const char* name) { g_last_kernel = name; }
+static thread_local int g_note_seq_ = 0;
+void rx_note_kernel(const char* name) { g_last_kernel = name; ++g_note_seq_; }
+int rx_note_seq(void) { return g_note_seq_; }
 extern "C" const char* rx_last_conv_kernel(void) { return g_last_kernel; }
 extern "C" int rx_abi_version(void) { return 1; }
 extern "C" int rx_device_arch_ok(void) {
@@ -212,6 +214,7 @@ extern "C" size_t rx_instnorm_stats_workspace(const rx_act* y) {
 
 extern "C" int rx_instnorm_stats(rx_dtype dt, const rx_act* y, float eps, float* stats, void* ws, size_t ws_bytes,
                                  void* stream) {
+  RX_RECORD(stream, [=, y_ = RxActV(y)](void* s) { return rx_instnorm_stats(dt, y_.p(), eps, stats, ws, ws_bytes, s); });
   int rc = check_vec_channels(y, dt, "rx_instnorm_stats");
   if (rc) return rc;
   if (!stats || !ws) RX_FAIL(RX_EINVAL, "rx_instnorm_stats: null stats/workspace");
@@ -256,6 +259,7 @@ extern "C" size_t rx_channel_sum_workspace(const rx_act* x) {
   return rx_reduce_ws_bytes(x->n, rx_act_voxels(x), x->c, 1);
 }
 extern "C" int rx_channel_sum(rx_dtype dt, const rx_act* x, float* out, void* ws, size_t ws_bytes, void* stream) {
+  RX_RECORD(stream, [=, x_ = RxActV(x)](void* s) { return rx_channel_sum(dt, x_.p(), out, ws, ws_bytes, s); });
   int rc = check_vec_channels(x, dt, "rx_channel_sum");
   if (rc) return rc;
   if (!out || !ws) RX_FAIL(RX_EINVAL, "rx_channel_sum: null out/workspace");
@@ -337,6 +341,7 @@ static int same_geom(const rx_act* a, const rx_act* b) {
 
 extern "C" int rx_instnorm_act_fwd(rx_dtype dt, const rx_act* y, const float* stats, const rx_act* residual,
                                    const rx_act* out, float slope, void* stream) {
+  RX_RECORD(stream, [=, y_ = RxActV(y), residual_ = RxActV(residual), out_ = RxActV(out)](void* s) { return rx_instnorm_act_fwd(dt, y_.p(), stats, residual_.p(), out_.p(), slope, s); });
   int rc = check_vec_channels(y, dt, "rx_instnorm_act_fwd(y)");
   if (rc) return rc;
   rc = check_vec_channels(out, dt, "rx_instnorm_act_fwd(out)");
@@ -639,6 +644,7 @@ static long rx_in_small_max() {
 extern "C" int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out,
                                    float slope, const rx_act* dy, const rx_act* d_residual, int accumulate_residual, void* ws,
                                    size_t ws_bytes, void* stream) {
+  RX_RECORD(stream, [=, g_ = RxActV(g), y_ = RxActV(y), out_ = RxActV(out), dy_ = RxActV(dy), d_residual_ = RxActV(d_residual)](void* s) { return rx_instnorm_act_bwd(dt, g_.p(), y_.p(), stats, out_.p(), slope, dy_.p(), d_residual_.p(), accumulate_residual, ws, ws_bytes, s); });
   int rc;
   if ((rc = check_vec_channels(g, dt, "rx_instnorm_act_bwd(g)"))) return rc;
   if ((rc = check_vec_channels(y, dt, "rx_instnorm_act_bwd(y)"))) return rc;
@@ -730,6 +736,7 @@ void rx_inbwd_fused_finalize_launch(const float* partial, int N, int nchunks, in
 extern "C" int rx_instnorm_act_bwd_apply(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out, float slope,
                                          const float* m12, const rx_act* dy, const rx_act* d_residual, int accumulate_residual,
                                          void* stream) {
+  RX_RECORD(stream, [=, g_ = RxActV(g), y_ = RxActV(y), out_ = RxActV(out), dy_ = RxActV(dy), d_residual_ = RxActV(d_residual)](void* s) { return rx_instnorm_act_bwd_apply(dt, g_.p(), y_.p(), stats, out_.p(), slope, m12, dy_.p(), d_residual_.p(), accumulate_residual, s); });
   int rc;
   if ((rc = check_vec_channels(g, dt, "rx_instnorm_act_bwd_apply(g)"))) return rc;
   if ((rc = check_vec_channels(y, dt, "rx_instnorm_act_bwd_apply(y)"))) return rc;
@@ -767,6 +774,7 @@ extern "C" int rx_instnorm_act_bwd_apply(rx_dtype dt, const rx_act* g, const rx_
 
 extern "C" int rx_instnorm_fwd(rx_dtype dt, const rx_act* y, float eps, float* stats, const rx_act* residual, const rx_act* out,
                                float slope, void* ws, size_t ws_bytes, void* stream) {
+  RX_RECORD(stream, [=, y_ = RxActV(y), residual_ = RxActV(residual), out_ = RxActV(out)](void* s) { return rx_instnorm_fwd(dt, y_.p(), eps, stats, residual_.p(), out_.p(), slope, ws, ws_bytes, s); });
   int rc;
   if ((rc = check_vec_channels(y, dt, "rx_instnorm_fwd(y)"))) return rc;
   const long V = rx_act_voxels(y);
@@ -866,6 +874,7 @@ static int check_pool(const rx_act* big, const rx_act* small, const int32_t f[3]
 }
 
 extern "C" int rx_avgpool_fwd(rx_dtype dt, const rx_act* x, const rx_act* y, const int32_t stride[3], void* stream) {
+  RX_RECORD(stream, [=, x_ = RxActV(x), y_ = RxActV(y), stride_ = RxI3V(stride)](void* s) { return rx_avgpool_fwd(dt, x_.p(), y_.p(), stride_.v, s); });
   int rc;
   if ((rc = check_vec_channels(x, dt, "rx_avgpool_fwd(x)"))) return rc;
   if ((rc = check_vec_channels(y, dt, "rx_avgpool_fwd(y)"))) return rc;
@@ -934,6 +943,7 @@ __global__ __launch_bounds__(256) void in_act_pool_fwd_kernel(const T* __restric
 
 extern "C" int rx_instnorm_act_pool_fwd(rx_dtype dt, const rx_act* y, const float* stats, const rx_act* residual, const rx_act* out,
                                         const rx_act* pooled, const int32_t stride[3], float slope, void* stream) {
+  RX_RECORD(stream, [=, y_ = RxActV(y), residual_ = RxActV(residual), out_ = RxActV(out), pooled_ = RxActV(pooled), stride_ = RxI3V(stride)](void* s) { return rx_instnorm_act_pool_fwd(dt, y_.p(), stats, residual_.p(), out_.p(), pooled_.p(), stride_.v, slope, s); });
   int rc;
   if ((rc = check_vec_channels(y, dt, "rx_instnorm_act_pool_fwd(y)"))) return rc;
   if ((rc = check_vec_channels(out, dt, "rx_instnorm_act_pool_fwd(out)"))) return rc;
@@ -966,6 +976,7 @@ extern "C" int rx_instnorm_act_pool_fwd(rx_dtype dt, const rx_act* y, const floa
 
 extern "C" int rx_avgpool_bwd(rx_dtype dt, const rx_act* dy, const rx_act* dx, const int32_t stride[3], int accumulate,
                               void* stream) {
+  RX_RECORD(stream, [=, dy_ = RxActV(dy), dx_ = RxActV(dx), stride_ = RxI3V(stride)](void* s) { return rx_avgpool_bwd(dt, dy_.p(), dx_.p(), stride_.v, accumulate, s); });
   int rc;
   if ((rc = check_vec_channels(dx, dt, "rx_avgpool_bwd(dx)"))) return rc;
   if ((rc = check_vec_channels(dy, dt, "rx_avgpool_bwd(dy)"))) return rc;
@@ -1038,6 +1049,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
 
 extern "C" int rx_head_fwd(rx_dtype dt, const rx_act* x, const float* w, const float* b, int k, float* out_ncdhw, int act,
                            void* stream) {
+  RX_RECORD(stream, [=, x_ = RxActV(x)](void* s) { return rx_head_fwd(dt, x_.p(), w, b, k, out_ncdhw, act, s); });
   int rc;
   if ((rc = check_vec_channels(x, dt, "rx_head_fwd"))) return rc;
   if (!w || !b || !out_ncdhw) RX_FAIL(RX_EINVAL, "rx_head_fwd: null pointer");
@@ -1129,6 +1141,7 @@ extern "C" size_t rx_head_bwd_workspace(const rx_act* x, int k) {
 
 extern "C" int rx_head_bwd(rx_dtype dt, const float* dout_ncdhw, const rx_act* x, const float* w, int k, const rx_act* dx, float* dw,
                            float* db, void* ws, size_t ws_bytes, void* stream) {
+  RX_RECORD(stream, [=, x_ = RxActV(x), dx_ = RxActV(dx)](void* s) { return rx_head_bwd(dt, dout_ncdhw, x_.p(), w, k, dx_.p(), dw, db, ws, ws_bytes, s); });
   int rc;
   if ((rc = check_vec_channels(x, dt, "rx_head_bwd(x)"))) return rc;
   if (dx) {
@@ -1249,6 +1262,7 @@ __global__ __launch_bounds__(256) void in_act_head_fwd_kernel(const T* __restric
 // Same `out` bit for bit and the same logits to fp32 round-off as rx_instnorm_act_fwd followed by rx_head_fwd.  K <= 4, 64 % (C / 8) == 0.
 extern "C" int rx_instnorm_act_head_fwd(rx_dtype dt, const rx_act* y, const float* stats, const rx_act* out, float slope,
                                         const float* head_w, const float* head_b, int k, float* out_ncdhw, int act, void* stream) {
+  RX_RECORD(stream, [=, y_ = RxActV(y), out_ = RxActV(out)](void* s) { return rx_instnorm_act_head_fwd(dt, y_.p(), stats, out_.p(), slope, head_w, head_b, k, out_ncdhw, act, s); });
   int rc = check_vec_channels(y, dt, "rx_instnorm_act_head_fwd(y)");
   if (rc) return rc;
   if ((rc = check_vec_channels(out, dt, "rx_instnorm_act_head_fwd(out)"))) return rc;
@@ -1371,6 +1385,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_head_kernel(const float*
 // out = NULL).  K <= 4.
 extern "C" int rx_instnorm_act_bwd_head(rx_dtype dt, const float* dout_ncdhw, int k, const float* head_w, const rx_act* y,
                                         const float* stats, float slope, const rx_act* dy, void* ws, size_t ws_bytes, void* stream) {
+  RX_RECORD(stream, [=, y_ = RxActV(y), dy_ = RxActV(dy)](void* s) { return rx_instnorm_act_bwd_head(dt, dout_ncdhw, k, head_w, y_.p(), stats, slope, dy_.p(), ws, ws_bytes, s); });
   int rc;
   if ((rc = check_vec_channels(y, dt, "rx_instnorm_act_bwd_head(y)"))) return rc;
   if ((rc = check_vec_channels(dy, dt, "rx_instnorm_act_bwd_head(dy)"))) return rc;
@@ -1523,6 +1538,7 @@ int rx_stem_fwd_mfma_try(rx_dtype dt, const float* x, int n, int cin, int z, int
 
 extern "C" int rx_stem_conv_fwd(rx_dtype dt, const float* x_ncdhw, int n, int cin, int z, int y, int x, const float* w,
                                 const float* bias, const rx_act* out, const int32_t kernel[3], void* stream) {
+  RX_RECORD(stream, [=, out_ = RxActV(out), kernel_ = RxI3V(kernel)](void* s) { return rx_stem_conv_fwd(dt, x_ncdhw, n, cin, z, y, x, w, bias, out_.p(), kernel_.v, s); });
   int rc;
   if ((rc = check_vec_channels(out, dt, "rx_stem_conv_fwd(out)"))) return rc;
   if ((rc = check_kernel13(kernel, "rx_stem_conv_fwd"))) return rc;
@@ -1661,6 +1677,7 @@ extern "C" size_t rx_stem_conv_bwd_weight_workspace(int cin, int cout, int taps)
 
 extern "C" int rx_stem_conv_bwd_weight(rx_dtype dt, const float* x_ncdhw, int n, int cin, int z, int y, int x, const rx_act* dy, float* dw,
                                        const int32_t kernel[3], void* ws, size_t ws_bytes, void* stream) {
+  RX_RECORD(stream, [=, dy_ = RxActV(dy), kernel_ = RxI3V(kernel)](void* s) { return rx_stem_conv_bwd_weight(dt, x_ncdhw, n, cin, z, y, x, dy_.p(), dw, kernel_.v, ws, ws_bytes, s); });
   int rc;
   if ((rc = check_vec_channels(dy, dt, "rx_stem_conv_bwd_weight(dy)"))) return rc;
   if ((rc = check_kernel13(kernel, "rx_stem_conv_bwd_weight"))) return rc;
@@ -1717,11 +1734,10 @@ extern "C" int rx_stem_conv_bwd_weight(rx_dtype dt, const float* x_ncdhw, int n,
 #endif
 
 template <typename T>
-__global__ __launch_bounds__(RX_PACK_THREADS) void pack_kernel(const float* __restrict__ w, int A, int B, int TT, unsigned inv_tt, T* __restrict__ same,
-                                                   int flip_same, T* __restrict__ swp, int flip_swap) {
+__device__ __forceinline__ void pack_tile(const float* __restrict__ w, int A, int B, int TT, unsigned inv_tt, T* __restrict__ same,
+                                          int flip_same, T* __restrict__ swp, int flip_swap, const int a0, const int b0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pack_smem[];
   T* L = reinterpret_cast<T*>(pack_smem);               // [TT][32 a][RX_PACK_PB]
-  const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
   const int rowlen = 32 * TT;
   const bool full = a0 + 32 <= A && b0 + 32 <= B && sizeof(T) == 2 && (B & 7) == 0 && (A & 7) == 0;
   // ---- load + convert + transpose into LDS
@@ -1783,6 +1799,40 @@ __global__ __launch_bounds__(RX_PACK_THREADS) void pack_kernel(const float* __re
       }
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(RX_PACK_THREADS) void pack_kernel(const float* __restrict__ w, int A, int B, int TT, unsigned inv_tt, T* __restrict__ same,
+                                                   int flip_same, T* __restrict__ swp, int flip_swap) {
+  pack_tile<T>(w, A, B, TT, inv_tt, same, flip_same, swp, flip_swap, blockIdx.y * 32, blockIdx.x * 32);
+}
+
+// Table-driven pack: up to RX_PM_MAX weight tensors per launch (pointer / shape table in the kernel arguments, workgroup ->
+// tensor by binary search over the first-tile index, as adamw_multi_kernel does).  A cfg2 step re-packs 66 tensors; one
+// launch each averaged 17 us (1.13 ms per step on the side stream, 1.5 TB/s: the small tensors are launch-bound).
+#define RX_PM_MAX 40
+struct PackMulti {
+  const float* w[RX_PM_MAX];
+  void* same[RX_PM_MAX];
+  void* swp[RX_PM_MAX];
+  int A[RX_PM_MAX], B[RX_PM_MAX], TT[RX_PM_MAX];
+  unsigned inv_tt[RX_PM_MAX];
+  int start[RX_PM_MAX + 1];       // first workgroup of tensor i; start[count] = grid size
+  int count;
+};
+
+template <typename T>
+__global__ __launch_bounds__(RX_PACK_THREADS) void pack_multi_kernel(const PackMulti tab) {
+  int lo = 0, hi = tab.count - 1;
+  const int blk = blockIdx.x;
+  while (lo < hi) {               // last i with start[i] <= blk
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab.start[mid] <= blk) lo = mid; else hi = mid - 1;
+  }
+  const int i = lo, local = blk - tab.start[i];
+  const int nb = (tab.B[i] + 31) >> 5;
+  const int ta = local / nb, tb = local - ta * nb;
+  pack_tile<T>(tab.w[i], tab.A[i], tab.B[i], tab.TT[i], tab.inv_tt[i], (T*)tab.same[i], 0, (T*)tab.swp[i], 0, ta * 32, tb * 32);
 }
 
 // ---- AdamW fused with the weight re-pack (and with gradient clipping) ------------------------------------------------
@@ -2157,10 +2207,57 @@ static int pack_generic(rx_dtype dt, const float* w, int A, int B, int TT, void*
 }
 
 extern "C" int rx_pack_conv_weight(rx_dtype dt, const float* w, int co, int ci, int taps, void* w_fwd, void* w_bwd, void* stream) {
+  RX_RECORD(stream, [=](void* s) { return rx_pack_conv_weight(dt, w, co, ci, taps, w_fwd, w_bwd, s); });
   // w (Co,Ci,T): w_fwd[t][co][ci] = same; w_bwd[t][ci][co] = swap
   return pack_generic(dt, w, co, ci, taps, w_fwd, 0, w_bwd, 0, stream);
 }
 extern "C" int rx_pack_convT_weight(rx_dtype dt, const float* w, int ci, int co, int taps, void* w_fwd, void* w_bwd, void* stream) {
+  RX_RECORD(stream, [=](void* s) { return rx_pack_convT_weight(dt, w, ci, co, taps, w_fwd, w_bwd, s); });
   // w (Ci,Co,T): w_fwd[t][co][ci] = swap; w_bwd[t][ci][co] = same
   return pack_generic(dt, w, ci, co, taps, w_bwd, 0, w_fwd, 0, stream);
+}
+
+// `count` weights in ceil(count / RX_PM_MAX) launches.  kind[i] 0: Conv3d weight (A = Co, B = Ci), 1: ConvTranspose3d weight
+// (A = Ci, B = Co); w_fwd[i] / w_bwd[i] as in rx_pack_conv_weight / rx_pack_convT_weight (either may be NULL).  HOST arrays.
+extern "C" int rx_pack_multi(rx_dtype dt, int count, const float* const* w, const int* kind, const int* A, const int* B, const int* taps,
+                             void* const* w_fwd, void* const* w_bwd, void* stream) {
+  if (count < 1 || !w || !kind || !A || !B || !taps || !w_fwd || !w_bwd) RX_FAIL(RX_EINVAL, "rx_pack_multi: bad arguments");
+  RxRecScope rx_scope__;
+  if (rx_scope__.rec) {       // host arrays: the program keeps its own copies
+    std::vector<const float*> w_(w, w + count);
+    std::vector<int> kind_(kind, kind + count), A_(A, A + count), B_(B, B + count), taps_(taps, taps + count);
+    std::vector<void*> f_(w_fwd, w_fwd + count), b_(w_bwd, w_bwd + count);
+    rx_rec_push(RxCmdFn([=](void* s) { return rx_pack_multi(dt, count, w_.data(), kind_.data(), A_.data(), B_.data(), taps_.data(), f_.data(), b_.data(), s); }),
+                stream, __func__);
+  }
+  for (int i = 0; i < count; ++i)
+    if (!w[i] || A[i] < 1 || B[i] < 1 || taps[i] < 1 || taps[i] > 27 || (kind[i] != 0 && kind[i] != 1))
+      RX_FAIL(RX_EINVAL, "rx_pack_multi: bad entry %d", i);
+  hipStream_t st = (hipStream_t)stream;
+  for (int i0 = 0; i0 < count; i0 += RX_PM_MAX) {
+    PackMulti t;
+    memset(&t, 0, sizeof(t));
+    const int k = count - i0 < RX_PM_MAX ? count - i0 : RX_PM_MAX;
+    long blocks = 0;
+    int max_tt = 1;
+    for (int j = 0; j < k; ++j) {
+      const int i = i0 + j;
+      t.w[j] = w[i], t.A[j] = A[i], t.B[j] = B[i], t.TT[j] = taps[i];
+      t.inv_tt[j] = (unsigned)(((1ull << 32) + taps[i] - 1) / taps[i]);
+      t.same[j] = kind[i] == 0 ? w_fwd[i] : w_bwd[i];
+      t.swp[j] = kind[i] == 0 ? w_bwd[i] : w_fwd[i];
+      t.start[j] = (int)blocks;
+      blocks += (long)((A[i] + 31) / 32) * ((B[i] + 31) / 32);
+      if (taps[i] > max_tt) max_tt = taps[i];
+    }
+    for (int q = k; q <= RX_PM_MAX; ++q) t.start[q] = (int)blocks;
+    t.count = k;
+    RX_DISPATCH_DTYPE(dt, T, {
+      const size_t lds = (size_t)max_tt * 32 * RX_PACK_PB * sizeof(T);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_multi_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((pack_multi_kernel<T>), dim3((unsigned)blocks), dim3(RX_PACK_THREADS), lds, st, t);
+    });
+  }
+  RX_CHECK_LAUNCH("rx_pack_multi");
+  return RX_OK;
 }

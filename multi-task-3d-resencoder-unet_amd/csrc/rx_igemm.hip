@@ -517,6 +517,7 @@ static void geom_out(IgemmGeom& g, const rx_act* a) {
 
 extern "C" int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, const float* bias, const rx_act* y,
                              const int32_t kernel[3], const int32_t stride[3], void* ws, size_t wsb, void* stream) {
+  RX_RECORD(stream, [=, x_ = RxActV(x), y_ = RxActV(y), kernel_ = RxI3V(kernel), stride_ = RxI3V(stride)](void* s) { return rx_conv3d_fwd(dt, x_.p(), w_fwd, bias, y_.p(), kernel_.v, stride_.v, ws, wsb, s); });
   if (!rx_act_ok_planar(x) || !rx_act_ok(y) || !w_fwd) RX_FAIL(RX_EINVAL, "rx_conv3d_fwd: bad arguments");
   int rc = check13(kernel, stride, "rx_conv3d_fwd");
   if (rc) return rc;
@@ -558,6 +559,7 @@ extern "C" int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, co
 extern "C" int rx_conv3d_bwd_data_instats(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx, const int32_t kernel[3],
                                           const int32_t stride[3], int accumulate, const rx_act* in_y, const float* in_stats, float slope,
                                           float* m12, int* fused, void* ws, size_t wsb, void* stream) {
+  RX_RECORD(stream, [=, dy_ = RxActV(dy), dx_ = RxActV(dx), kernel_ = RxI3V(kernel), stride_ = RxI3V(stride), in_y_ = RxActV(in_y)](void* s) { int fused_dummy = 0; return rx_conv3d_bwd_data_instats(dt, dy_.p(), w_bwd, dx_.p(), kernel_.v, stride_.v, accumulate, in_y_.p(), in_stats, slope, m12, &fused_dummy, ws, wsb, s); });
   if (!fused || !m12 || !in_stats || !rx_act_ok(in_y) || !ws) RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_data_instats: bad arguments");
   *fused = 0;
   if (!rx_act_ok(dy) || !rx_act_ok(dx) || !w_bwd) RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_data_instats: bad arguments");
@@ -593,6 +595,7 @@ extern "C" int rx_conv3d_bwd_data_instats(rx_dtype dt, const rx_act* dy, const v
 extern "C" int rx_conv3d_fwd_stats(rx_dtype dt, const rx_act* x, const void* w_fwd, const float* bias, const rx_act* y,
                                    const int32_t kernel[3], const int32_t stride[3], float eps, float* stats, void* ws, size_t wsb,
                                    void* stream) {
+  RX_RECORD(stream, [=, x_ = RxActV(x), y_ = RxActV(y), kernel_ = RxI3V(kernel), stride_ = RxI3V(stride)](void* s) { return rx_conv3d_fwd_stats(dt, x_.p(), w_fwd, bias, y_.p(), kernel_.v, stride_.v, eps, stats, ws, wsb, s); });
   if (!rx_act_ok_planar(x) || !rx_act_ok(y) || !w_fwd || !stats || !ws) RX_FAIL(RX_EINVAL, "rx_conv3d_fwd_stats: bad arguments");
   int rc = check13(kernel, stride, "rx_conv3d_fwd_stats");
   if (rc) return rc;
@@ -620,6 +623,7 @@ extern "C" int rx_conv3d_fwd_stats(rx_dtype dt, const rx_act* x, const void* w_f
 
 extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx, const int32_t kernel[3],
                                   const int32_t stride[3], int accumulate, void* ws, size_t wsb, void* stream) {
+  RX_RECORD(stream, [=, dy_ = RxActV(dy), dx_ = RxActV(dx), kernel_ = RxI3V(kernel), stride_ = RxI3V(stride)](void* s) { return rx_conv3d_bwd_data(dt, dy_.p(), w_bwd, dx_.p(), kernel_.v, stride_.v, accumulate, ws, wsb, s); });
   if (!rx_act_ok(dy) || !rx_act_ok_planar(dx) || !w_bwd) RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_data: bad arguments");
   int rc = check13(kernel, stride, "rx_conv3d_bwd_data");
   if (rc) return rc;
@@ -689,6 +693,7 @@ static int checkT(const int32_t s[3], const rx_act* small, const rx_act* big, co
 
 extern "C" int rx_convT3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, const float* bias, const rx_act* y,
                               const int32_t stride[3], void* ws, size_t wsb, void* stream) {
+  RX_RECORD(stream, [=, x_ = RxActV(x), y_ = RxActV(y), stride_ = RxI3V(stride)](void* s) { return rx_convT3d_fwd(dt, x_.p(), w_fwd, bias, y_.p(), stride_.v, ws, wsb, s); });
   if (!rx_act_ok(x) || !rx_act_ok(y) || !w_fwd) RX_FAIL(RX_EINVAL, "rx_convT3d_fwd: bad arguments");
   int rc = checkT(stride, x, y, "rx_convT3d_fwd");
   if (rc) return rc;
@@ -716,6 +721,7 @@ extern "C" int rx_convT3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, c
 
 extern "C" int rx_convT3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx, const int32_t stride[3],
                                    int accumulate, void* ws, size_t wsb, void* stream) {
+  RX_RECORD(stream, [=, dy_ = RxActV(dy), dx_ = RxActV(dx), stride_ = RxI3V(stride)](void* s) { return rx_convT3d_bwd_data(dt, dy_.p(), w_bwd, dx_.p(), stride_.v, accumulate, ws, wsb, s); });
   if (!rx_act_ok(dy) || !rx_act_ok(dx) || !w_bwd) RX_FAIL(RX_EINVAL, "rx_convT3d_bwd_data: bad arguments");
   int rc = checkT(stride, dx, dy, "rx_convT3d_bwd_data");
   if (rc) return rc;

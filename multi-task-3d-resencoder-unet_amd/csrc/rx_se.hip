@@ -411,6 +411,7 @@ extern "C" size_t rx_se_workspace(const rx_act* y) {
 
 extern "C" int rx_se_gate_fwd(rx_dtype dt, const rx_act* y, const float* stats, const float* path_scale, const rx_se_params* se, float* pooled,
                               float* hidden, float* gate, float* mult, void* ws, size_t ws_bytes, void* stream) {
+  RX_RECORD(stream, [=, y_ = RxActV(y), se_ = RxSeV(se)](void* s) { return rx_se_gate_fwd(dt, y_.p(), stats, path_scale, se_.p(), pooled, hidden, gate, mult, ws, ws_bytes, s); });
   int rc = se_check(y, dt, "rx_se_gate_fwd(y)");
   if (rc) return rc;
   if (!mult) RX_FAIL(RX_EINVAL, "rx_se_gate_fwd: null mult");
@@ -442,6 +443,7 @@ extern "C" int rx_se_gate_fwd(rx_dtype dt, const rx_act* y, const float* stats, 
 
 extern "C" int rx_instnorm_gate_act_fwd(rx_dtype dt, const rx_act* y, const float* stats, const float* mult, int keep_x, const rx_act* residual,
                                         const rx_act* out, float slope, void* stream) {
+  RX_RECORD(stream, [=, y_ = RxActV(y), residual_ = RxActV(residual), out_ = RxActV(out)](void* s) { return rx_instnorm_gate_act_fwd(dt, y_.p(), stats, mult, keep_x, residual_.p(), out_.p(), slope, s); });
   int rc;
   if ((rc = se_check(y, dt, "rx_instnorm_gate_act_fwd(y)"))) return rc;
   if ((rc = se_check(out, dt, "rx_instnorm_gate_act_fwd(out)"))) return rc;
@@ -478,6 +480,7 @@ extern "C" int rx_se_gate_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, con
                               const float* path_scale, const rx_se_params* se, const float* pooled, const float* hidden, const float* gate,
                               const float* mult, float* dadd, float* m12, float* dw1, float* db1, float* dw2, float* db2, void* ws,
                               size_t ws_bytes, void* stream) {
+  RX_RECORD(stream, [=, g_ = RxActV(g), y_ = RxActV(y), out_ = RxActV(out), se_ = RxSeV(se)](void* s) { return rx_se_gate_bwd(dt, g_.p(), y_.p(), stats, out_.p(), slope, path_scale, se_.p(), pooled, hidden, gate, mult, dadd, m12, dw1, db1, dw2, db2, ws, ws_bytes, s); });
   int rc;
   if ((rc = se_check(g, dt, "rx_se_gate_bwd(g)"))) return rc;
   if ((rc = se_check(y, dt, "rx_se_gate_bwd(y)"))) return rc;
@@ -526,6 +529,7 @@ extern "C" int rx_se_gate_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, con
 extern "C" int rx_instnorm_gate_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out, float slope,
                                         const float* mult, const float* dadd, const float* m12, int keep_x, const rx_act* dy,
                                         const rx_act* d_residual, int accumulate_residual, void* stream) {
+  RX_RECORD(stream, [=, g_ = RxActV(g), y_ = RxActV(y), out_ = RxActV(out), dy_ = RxActV(dy), d_residual_ = RxActV(d_residual)](void* s) { return rx_instnorm_gate_act_bwd(dt, g_.p(), y_.p(), stats, out_.p(), slope, mult, dadd, m12, keep_x, dy_.p(), d_residual_.p(), accumulate_residual, s); });
   int rc;
   if ((rc = se_check(g, dt, "rx_instnorm_gate_act_bwd(g)"))) return rc;
   if ((rc = se_check(y, dt, "rx_instnorm_gate_act_bwd(y)"))) return rc;

@@ -323,6 +323,7 @@ extern "C" size_t rx_conv3d_bwd_weight_workspace(const rx_act* x, const rx_act* 
 
 extern "C" int rx_conv3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw, const int32_t kernel[3],
                                     const int32_t stride[3], void* ws, size_t ws_bytes, void* stream) {
+  RX_RECORD(stream, [=, x_ = RxActV(x), dy_ = RxActV(dy), kernel_ = RxI3V(kernel), stride_ = RxI3V(stride)](void* s) { return rx_conv3d_bwd_weight(dt, x_.p(), dy_.p(), dw, kernel_.v, stride_.v, ws, ws_bytes, s); });
   if (!rx_act_ok_planar(x) || !rx_act_ok(dy)) RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_weight: bad arguments");
   for (int i = 0; i < 3; ++i) {
     if (kernel[i] != 1 && kernel[i] != 3) RX_FAIL(RX_EUNSUPPORTED, "rx_conv3d_bwd_weight: kernel sizes must be 1 or 3");
@@ -362,6 +363,7 @@ extern "C" size_t rx_convT3d_bwd_weight_workspace(const rx_act* x, const rx_act*
 
 extern "C" int rx_convT3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw, const int32_t stride[3], void* ws,
                                      size_t ws_bytes, void* stream) {
+  RX_RECORD(stream, [=, x_ = RxActV(x), dy_ = RxActV(dy), stride_ = RxI3V(stride)](void* s) { return rx_convT3d_bwd_weight(dt, x_.p(), dy_.p(), dw, stride_.v, ws, ws_bytes, s); });
   if (!rx_act_ok(x) || !rx_act_ok(dy)) RX_FAIL(RX_EINVAL, "rx_convT3d_bwd_weight: bad arguments");
   for (int i = 0; i < 3; ++i)
     if (stride[i] != 1 && stride[i] != 2) RX_FAIL(RX_EUNSUPPORTED, "rx_convT3d_bwd_weight: strides must be 1 or 2");

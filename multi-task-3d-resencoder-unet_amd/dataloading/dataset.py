@@ -18,6 +18,10 @@ from . import zarr_lite
 
 
 class SyntheticPatchDataset(Dataset):
+    """SURVEY 8(d)'s synthetic patches.  `dataset_config.synthetic_pool` (default 16) distinct patches are generated once per
+    process and handed out round-robin: drawing 2 x 128^3 uniform numbers per item costs ~60 ms of one CPU core, which would make
+    a 128^3 training run loader-bound at ~8 patches/s; 0 = draw every item afresh."""
+
     def __init__(self, mgr, length=None, seed=1234):
         self.mgr = mgr
         self.patch = tuple(mgr.train_patch_size)
@@ -25,11 +29,21 @@ class SyntheticPatchDataset(Dataset):
         self.tasks = mgr.tasks
         self.length = int(length if length is not None else mgr.dataset_config.get("synthetic_length", 64))
         self.seed = seed
+        self.pool = int(mgr.dataset_config.get("synthetic_pool", 16))
+        self._cache = {}
 
     def __len__(self):
         return self.length
 
     def __getitem__(self, idx):
+        if self.pool > 0:
+            key = int(idx) % self.pool
+            if key not in self._cache:
+                self._cache[key] = self._make(key)
+            return dict(self._cache[key])
+        return self._make(idx)
+
+    def _make(self, idx):
         g = torch.Generator().manual_seed(self.seed + int(idx))
         item = {"image": torch.rand((self.cin, *self.patch), generator=g)}
         seg = (torch.rand((1, *self.patch), generator=g) > 0.8).float()

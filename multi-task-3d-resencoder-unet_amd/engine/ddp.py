@@ -52,6 +52,7 @@ class GradSync:
         self._of: Dict[int, _Bucket] = {}
         self._params = None
         self._side = None
+        self.persistent = False         # set by a plan that replays a recorded backward: bucket storage must not move
         self.require_sync = True        # False: accumulate locally, no collective (see no_sync)
         self._syncing = True            # value of require_sync latched by begin() for the running backward
         self.stats = dict(buckets=0, bytes=0, collectives=0)
@@ -98,7 +99,8 @@ class GradSync:
         self._syncing = bool(self.require_sync)
         dev = plan.params[0].device
         for b in self._cur:
-            b.flat = torch.empty(b.numel, dtype=torch.float32, device=dev)
+            if not (self.persistent and b.flat is not None and b.flat.device == dev):
+                b.flat = torch.empty(b.numel, dtype=torch.float32, device=dev)
             b.pending = len(b.idxs)
             b.work = None
             b.streams = {}
@@ -130,7 +132,8 @@ class GradSync:
             b.flat.add_(b.carry)
             b.carry = None
         if not self._syncing:
-            b.carry = b.flat            # stays local; the stepping micro-batch picks it up
+            # stays local; the stepping micro-batch picks it up (a copy when the bucket storage is reused by the next backward)
+            b.carry = b.flat.clone() if self.persistent else b.flat
             return
         if self.world == 1:
             return

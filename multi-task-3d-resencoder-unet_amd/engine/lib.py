@@ -42,6 +42,7 @@ _SIGNATURES = {
     "rx_last_conv_kernel": (c_char_p, []),
     "rx_pack_conv_weight": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rx_pack_convT_weight": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rx_pack_multi": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rx_conv_workspace_hint": (c_size_t, []),
     "rx_conv3d_fwd": (c_int, [c_int, _P, c_void_p, c_void_p, _P, I3, I3, c_void_p, c_size_t, c_void_p]),
     "rx_conv3d_fwd_stats": (c_int, [c_int, _P, c_void_p, c_void_p, _P, I3, I3, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -99,6 +100,18 @@ _SIGNATURES = {
                               c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rx_adamw_flat_multi": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double,
                                     c_double, c_double, c_int, c_void_p]),
+    "rx_prog_create": (c_void_p, []),
+    "rx_prog_destroy": (None, [c_void_p]),
+    "rx_prog_begin": (c_int, [c_void_p, c_void_p, c_int]),
+    "rx_prog_end": (c_int, [c_void_p]),
+    "rx_prog_len": (c_int, [c_void_p]),
+    "rx_prog_cmd_name": (c_char_p, [c_void_p, c_int]),
+    "rx_prog_cmd_kernel": (c_char_p, [c_void_p, c_int]),
+    "rx_prog_cmd_stream": (c_int, [c_void_p, c_int]),
+    "rx_prog_run": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "rx_event_new": (c_int, []),
+    "rx_event_record": (c_int, [c_int, c_void_p]),
+    "rx_stream_wait": (c_int, [c_int, c_void_p]),
     "rx_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_double, c_int,
                               c_long, c_void_p]),
 }

@@ -30,6 +30,8 @@ class LaunchProfiler:
     def __init__(self):
         self.pending = []
         self.groups = {}
+        self.pending_hbm = []
+        self.hbm = {}
 
     @staticmethod
     def igemm_name(vq, co):
@@ -45,6 +47,16 @@ class LaunchProfiler:
             name = kind + ":" + load().rx_last_conv_kernel().decode()
         self.pending.append((name, flops, launches, e0, e1))
 
+    def run_bytes(self, name, nbytes, fn):
+        """an HBM-bound launch (or launch pair): `nbytes` = ALGORITHMIC bytes (every operand tensor touched once at its storage
+        type); timed like the convs, on the stream it is enqueued on"""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.pending_hbm.append((name, float(nbytes), e0, e1))
+        return r
+
     def collect(self):
         torch.cuda.synchronize()
         for name, flops, launches, e0, e1 in self.pending:
@@ -54,7 +66,75 @@ class LaunchProfiler:
             g["calls"] += 1
             g["launches"] += launches
         self.pending = []
+        for name, nbytes, e0, e1 in self.pending_hbm:
+            g = self.hbm.setdefault(name, dict(ms=0.0, bytes=0.0, calls=0))
+            g["ms"] += e0.elapsed_time(e1)
+            g["bytes"] += nbytes
+            g["calls"] += 1
+        self.pending_hbm = []
         return self.groups
+
+
+# ---- numbered events + launch programs (include/rxunet.h "launch programs") -------------------------------------------
+def event_new():
+    return int(load().rx_event_new())
+
+
+def _sp(stream):
+    return stream_ptr() if stream is None else c_void_p(stream.cuda_stream)
+
+
+def event_record(slot, stream=None):
+    """record numbered event `slot` on `stream` (default: torch's current stream)"""
+    check(load().rx_event_record(slot, _sp(stream)), "rx_event_record")
+
+
+def stream_wait(slot, stream=None):
+    """make `stream` (default: current) wait for the last record of event `slot`"""
+    check(load().rx_stream_wait(slot, _sp(stream)), "rx_stream_wait")
+
+
+class Program:
+    """a recorded launch list (rx_prog): `with prog.recording(streams): <ordinary ops calls>` executes AND records them;
+    `prog.run(streams)` replays them from C"""
+
+    def __init__(self):
+        self.h = c_void_p(load().rx_prog_create())
+        self.n = 0
+
+    def __del__(self):
+        try:
+            if self.h:
+                load().rx_prog_destroy(self.h)
+        except Exception:
+            pass
+
+    @staticmethod
+    def _table(streams):
+        import ctypes
+        return (ctypes.c_void_p * len(streams))(*[s.cuda_stream for s in streams])
+
+    def begin(self, streams):
+        check(load().rx_prog_begin(self.h, self._table(streams), len(streams)), "rx_prog_begin")
+
+    def end(self):
+        check(load().rx_prog_end(self.h), "rx_prog_end")
+        self.n = int(load().rx_prog_len(self.h))
+
+    def __len__(self):
+        return int(load().rx_prog_len(self.h))
+
+    def run(self, streams, first=0, last=-1):
+        check(load().rx_prog_run(self.h, first, last, self._table(streams), len(streams), None), "rx_prog_run")
+
+    def run_timed(self, streams):
+        """profiling replay: per-command milliseconds (HIP events on each command's stream; synchronises)"""
+        import ctypes
+        ms = (ctypes.c_float * max(self.n, 1))()
+        check(load().rx_prog_run(self.h, 0, -1, self._table(streams), len(streams), ms), "rx_prog_run")
+        lib = load()
+        return [(lib.rx_prog_cmd_name(self.h, i).decode(), lib.rx_prog_cmd_kernel(self.h, i).decode(),
+                 int(lib.rx_prog_cmd_stream(self.h, i)), float(ms[i])) for i in range(self.n)]
 
 
 def workspace(nbytes=None, device=None):
@@ -203,6 +283,27 @@ def pack_convT_weight(w, dtype, w_fwd=None, w_bwd=None, want_fwd=True, want_bwd=
     check(load().rx_pack_convT_weight(_code(dtype), _ptr(w), ci, co, taps, _ptr(w_fwd if want_fwd else None),
                                       _ptr(w_bwd if want_bwd else None), stream_ptr()), "rx_pack_convT_weight")
     return w_fwd, w_bwd
+
+
+def pack_weights_multi(items, dtype):
+    """items: [(w fp32 contiguous, kind 0 conv / 1 convT, w_fwd or None, w_bwd or None)] -> ONE launch per 40 tensors
+    (rx_pack_multi).  5-D weights (a 2-D net's are unsqueezed by the caller)."""
+    import ctypes
+    n = len(items)
+    if n == 0:
+        return
+    VP, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    wp = VP(*[w.data_ptr() for w, _, _, _ in items])
+    kind = IA(*[k for _, k, _, _ in items])
+    A = IA(*[w.shape[0] for w, _, _, _ in items])
+    B = IA(*[w.shape[1] for w, _, _, _ in items])
+    T = IA(*[w[0, 0].numel() for w, _, _, _ in items])
+    fw = VP(*[(f.data_ptr() if f is not None else None) for _, _, f, _ in items])
+    bw = VP(*[(b.data_ptr() if b is not None else None) for _, _, _, b in items])
+    esz = torch.empty((), dtype=dtype).element_size()
+    nbytes = sum(w.numel() * (4 + (esz if f is not None else 0) + (esz if b is not None else 0)) for w, _, f, b in items)
+    timed_bytes("pack", nbytes, lambda: check(load().rx_pack_multi(_code(dtype), n, wp, kind, A, B, T, fw, bw, stream_ptr()),
+                                             "rx_pack_multi"))
 
 
 # ---- convolutions -----------------------------------------------------------------------------
@@ -489,3 +590,75 @@ def masked_cosine_loss_bwd(pred, target, coef, grad_loss):
     check(load().rx_masked_cosine_loss_bwd(_ptr(pred), _ptr(target), n, c, v, _ptr(coef), _ptr(grad_loss), _ptr(dpred),
                                            stream_ptr()), "rx_masked_cosine_loss_bwd")
     return dpred
+
+
+# ---- bench.py's `hbm` block: the HBM-bound launches timed against their ALGORITHMIC bytes ---------------------------
+# (every operand tensor touched once at its storage type, SURVEY 8(d): a standalone statistics pass or the first pass of a
+# two-pass backward is extra TIME, not extra algorithmic bytes).  Wrappers cost one Python call when no profiler is set.
+def timed_bytes(name, nbytes, fn):
+    if _PROF is None:
+        return fn()
+    return _PROF.run_bytes(name, nbytes, fn)
+
+
+def _tb(a):
+    """bytes of one pass over the channels an activation view addresses (0 for None)"""
+    return 0 if a is None else a.dims[0] * a.voxels * a.c * a.t.element_size()
+
+
+def _hbm(label, nbytes):
+    def deco(f):
+        def wrapped(*a, **k):
+            if _PROF is None:
+                return f(*a, **k)
+            return _PROF.run_bytes(label, nbytes(*a, **k), lambda: f(*a, **k))
+        wrapped.__name__, wrapped.__doc__ = f.__name__, f.__doc__
+        return wrapped
+    return deco
+
+
+def _bwd_bytes(g, y, out, dy, d_residual, acc):
+    return _tb(g) + _tb(y) + _tb(dy) + _tb(out) + _tb(d_residual) * (2 if acc else 1)
+
+
+def _pack_bytes(w, dtype, w_fwd=None, w_bwd=None, want_fwd=True, want_bwd=True):
+    e = torch.empty((), dtype=dtype).element_size()
+    return w.numel() * (4 + (e if want_fwd else 0) + (e if want_bwd else 0))
+
+
+instnorm_stats = _hbm("in_stats(colreduce)", lambda y, stats, eps=1e-5, ws=None: _tb(y))(instnorm_stats)
+instnorm_act_fwd = _hbm("in_act_fwd", lambda y, stats, out, slope=0.01, residual=None: _tb(y) + _tb(out) + _tb(residual))(instnorm_act_fwd)
+instnorm_fwd = _hbm("in_fwd(stats+apply)", lambda y, stats, out, slope=0.01, residual=None, eps=1e-5, ws=None:
+                    _tb(y) + _tb(out) + _tb(residual))(instnorm_fwd)
+instnorm_act_bwd = _hbm("in_act_bwd(colreduce+apply)",
+                        lambda g, y, stats, out, dy, slope=0.01, d_residual=None, accumulate_residual=False, ws=None:
+                        _bwd_bytes(g, y, out, dy, d_residual, accumulate_residual))(instnorm_act_bwd)
+instnorm_act_bwd_apply = _hbm("in_act_bwd_apply",
+                              lambda g, y, stats, out, dy, m12, slope=0.01, d_residual=None, accumulate_residual=False:
+                              _bwd_bytes(g, y, out, dy, d_residual, accumulate_residual))(instnorm_act_bwd_apply)
+se_gate_fwd = _hbm("se_gate_fwd(linesum+gate)", lambda y, *a, **k: _tb(y))(se_gate_fwd)
+instnorm_gate_act_fwd = _hbm("in_gate_act_fwd", lambda y, stats, mult, keep_x, out, slope=0.01, residual=None:
+                             _tb(y) + _tb(out) + _tb(residual))(instnorm_gate_act_fwd)
+se_gate_bwd = _hbm("se_gate_bwd(linesums+gate)", lambda g, y, stats, out, *a, **k: _tb(g) + _tb(y) + _tb(out))(se_gate_bwd)
+instnorm_gate_act_bwd = _hbm("in_gate_act_bwd",
+                             lambda g, y, stats, out, slope, mult, dadd, m12, keep_x, dy, d_residual=None, accumulate_residual=False:
+                             _bwd_bytes(g, y, out, dy, d_residual, accumulate_residual))(instnorm_gate_act_bwd)
+avgpool_fwd = _hbm("avgpool_fwd", lambda x, y, stride: _tb(x) + _tb(y))(avgpool_fwd)
+instnorm_act_pool_fwd = _hbm("in_act_pool_fwd", lambda y, stats, out, pooled, stride, slope=0.01, residual=None:
+                             _tb(y) + _tb(out) + _tb(pooled) + _tb(residual))(instnorm_act_pool_fwd)
+avgpool_bwd = _hbm("avgpool_bwd", lambda dy, dx, stride, accumulate=False: _tb(dy) + _tb(dx) * (2 if accumulate else 1))(avgpool_bwd)
+head_fwd = _hbm("head_fwd", lambda x, w, b, out_ncdhw, act=0: _tb(x) + out_ncdhw.numel() * 4)(head_fwd)
+head_bwd = _hbm("head_bwd", lambda dout_ncdhw, x, w, dx, dw, db, ws=None: dout_ncdhw.numel() * 4 + _tb(x) + _tb(dx))(head_bwd)
+instnorm_act_head_fwd = _hbm("in_act_head_fwd", lambda y, stats, out, w, b, out_ncdhw, act, slope=0.01:
+                             _tb(y) + _tb(out) + out_ncdhw.numel() * 4)(instnorm_act_head_fwd)
+instnorm_act_bwd_head = _hbm("in_act_bwd_head(colreduce+apply)", lambda dout_ncdhw, w, y, stats, dy, slope=0.01, ws=None:
+                             dout_ncdhw.numel() * 4 + _tb(y) + _tb(dy))(instnorm_act_bwd_head)
+channel_sum = _hbm("channel_sum", lambda x, out, ws=None: _tb(x))(channel_sum)
+pack_conv_weight = _hbm("pack", _pack_bytes)(pack_conv_weight)
+pack_convT_weight = _hbm("pack", _pack_bytes)(pack_convT_weight)
+stem_conv_fwd = _hbm("stem_conv_fwd", lambda x_ncdhw, w, bias, out, kernel: x_ncdhw.numel() * 4 + _tb(out))(stem_conv_fwd)
+stem_conv_bwd_weight = _hbm("stem_conv_bwd_weight", lambda x_ncdhw, dy, dw, kernel, ws=None: x_ncdhw.numel() * 4 + _tb(dy))(stem_conv_bwd_weight)
+convT3d_fwd = _hbm("convT_fwd", lambda x, w_fwd, bias, y, stride, ws=None: _tb(x) + _tb(y))(convT3d_fwd)
+convT3d_bwd_data = _hbm("convT_bwd_data", lambda dy, w_bwd, dx, stride, accumulate=False, ws=None:
+                        _tb(dy) + _tb(dx) * (2 if accumulate else 1))(convT3d_bwd_data)
+convT3d_bwd_weight = _hbm("convT_bwd_weight", lambda x, dy, dw, stride, ws=None: _tb(x) + _tb(dy))(convT3d_bwd_weight)

@@ -133,7 +133,31 @@ class Plan:
         self._side = None
         self._ws2 = None
         self._dy_turn: Dict[tuple, int] = {}
-        self._dy_free: Dict[int, "torch.cuda.Event"] = {}
+        # Cross-stream ordering goes through the library's NUMBERED events (rx_event_record / rx_stream_wait) in every mode, so
+        # that a recorded launch program (below) contains exactly what an eager pass issues.  _dy_free: dy buffers whose last
+        # side-stream reader has recorded its event and that the main stream must wait for before writing them again.
+        self._dy_free: Dict[int, int] = {}
+        self._dy_ev: Dict[int, int] = {}          # id(dy tensor) -> event slot
+        self._ev_fork = None                      # main -> side
+        self._ev_join = None                      # side -> main
+        self._pack_groups = None                  # [(entries, event slot)] in first-use order (static per plan)
+        self._gates: List[dict] = []              # SqueezeExcite / DropPath state of every gated block, forward order
+        # Launch programs (default on; RX_PROGRAMS=0 = one ctypes call per launch): the forward / backward lists are static, so
+        # after two eager passes each is RECORDED once by the library while it executes (rx_prog_begin/end) and every later
+        # step replays it with one C call -- the same launches on the same two streams, without ~700 host-language calls
+        # (8 ms of host time per cfg2 step; the 64^3 configuration was host-bound).
+        self.use_programs = os.environ.get("RX_PROGRAMS", "1") == "1"
+        self._pstate: Dict[tuple, dict] = {}
+        self._gflat = None                        # persistent gradient storage (program mode: recorded pointers must not move)
+        self._gviews: Dict[int, torch.Tensor] = {}
+        self._marks: List[tuple] = []             # (command index, parameter index, produced on the side stream?) while recording
+        self._recording = None
+        self._on_side = False
+        self._use_gstore = False
+        self._gflat_range = (0, 0)
+        self._pack_slots: List[int] = []
+        self._unstable_params = False
+        self._ws_refs: List[object] = []
         self._raw_seen = None                 # last `net._raw_param_event` (engine/streamed_step.py) this plan waited for
         # HIP graphs (opt-in: RX_GRAPHS=1 or plan.use_graphs = True): the forward / backward launch lists are static
         # (fixed buffers, fixed shapes), so after two eager passes (lazy allocations, kernel attribute calls) each list
@@ -272,6 +296,8 @@ class Plan:
         if self.device.type == "cuda":
             need = 4 * (self.B * 256 * 2 * odims[2] * c + self.B * odims[2] * (3 * c + 64)) + 1024
             ops.workspace(need, self.device)
+        g["scale_now"] = None
+        self._gates.append(g)
         return g
 
     @staticmethod
@@ -487,7 +513,7 @@ class Plan:
                     def gstep(a=a):
                         g = a["gate"]
                         res = a["res"].act if a["res"] is not None else None
-                        g["scale_now"] = P._draw_path_scale(g)
+                        # g["scale_now"]: this step's DropPath factors, drawn at the start of the forward (_forward_body)
                         if g["se"] is None and g["scale_now"] is None:        # DropPath in eval: the plain block
                             ops.instnorm_fwd(a["y"].act, a["stats"], a["out"].act, a["slope"], res, a["eps"])
                             return
@@ -559,16 +585,22 @@ class Plan:
             # a FRESH tensor every backward (autograd may keep / accumulate into what we return); a gradient
             # synchroniser may hand out views of its flat buckets instead (engine/ddp.py)
             sync = P.grad_sync
-            g = sync.alloc(idx) if sync is not None else torch.empty_like(P.params[idx],
-                                                                          memory_format=torch.contiguous_format)
+            if sync is not None:
+                g = sync.alloc(idx)
+            elif P._use_gstore:             # program mode: the same storage every backward (see _grad_store)
+                g = P._gviews[idx]
+            else:
+                g = torch.empty_like(P.params[idx], memory_format=torch.contiguous_format)
             P._grads[idx] = g
             return g
 
         def done(idx):
+            if P._recording is not None:        # while a program is recorded: where in the command list the gradient is complete
+                P._marks.append((len(P._recording), idx, P._on_side))
             if P.grad_sync is not None:
                 P.grad_sync.ready(idx)
 
-        # events guarding the two dy slots of every shape: the side stream's last reader of a slot must be done
+        # events guarding the dy slots of every shape: the side stream's last reader of a slot must be done
         # before the main stream writes that slot again
         dy_free = self._dy_free
 
@@ -578,19 +610,25 @@ class Plan:
             if not (P.overlap_wgrad and P._side is not None):
                 fn(ops.workspace())
                 return
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            P._side.wait_event(ev)
-            with torch.cuda.stream(P._side):
-                fn(P._ws2)
-                fin = torch.cuda.Event()
-                fin.record(P._side)
-            dy_free[id(dy_act.t)] = fin
+            ops.event_record(P._ev_fork)              # main (current) stream
+            ops.stream_wait(P._ev_fork, P._side)
+            key = id(dy_act.t)
+            slot = P._dy_ev.get(key)
+            if slot is None:
+                slot = P._dy_ev[key] = ops.event_new()
+            P._on_side = True
+            try:
+                with torch.cuda.stream(P._side):
+                    fn(P._ws2)
+                    ops.event_record(slot)
+            finally:
+                P._on_side = False
+            dy_free[key] = slot
 
         def before_dy_write(dy_act):
-            ev = dy_free.pop(id(dy_act.t), None)
-            if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
+            slot = dy_free.pop(id(dy_act.t), None)
+            if slot is not None:
+                ops.stream_wait(slot)
 
         order = self.grad_order
 
@@ -784,62 +822,157 @@ class Plan:
         return at.gact
 
     # ------------------------------------------------------------------ run
+    def _ensure_side(self):
+        if self.device.type == "cuda" and self.overlap_wgrad and self._side is None:
+            self._side = side_stream(self.device)
+            self._ws2 = torch.empty(ops.workspace().numel(), dtype=torch.uint8, device=self.device)
+        if self._ev_fork is None and self.device.type == "cuda":
+            self._ev_fork, self._ev_join = ops.event_new(), ops.event_new()
+
     def _await_pack(self, ent):
-        ev = ent.get("event")
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-            ent["event"] = None
+        slot = ent.get("event")
+        if slot is not None:
+            ops.stream_wait(slot)
+            for e in ent["group"]:          # one event per pack group: the first consumer's wait covers them all (stream order)
+                e["event"] = None
+
+    def _packs_stale(self, force=False):
+        """Staleness: tensor version / address AND the model's weight epoch.  torch's FUSED optimizers (fused=True
+        Adam/AdamW/SGD: `_fused_adamw_` ...) update parameters WITHOUT bumping `Tensor._version`, so a version check alone
+        would keep the initial packed weights for a whole training run.  Every backward pass through the engine
+        therefore starts a new weight epoch (an optimizer step is what normally follows it) and all plans of the model
+        re-pack on their next forward; pure inference (no backward) keeps its packs."""
+        epoch = getattr(self.net, "_weights_epoch", 0)
+        return [e for e in self.packs
+                if force or e.get("epoch") != epoch
+                or not (e["version"] == e["param"]._version and e.get("ptr") == e["param"].data_ptr())]
 
     def refresh_packs(self, force=False):
-        """re-pack every parameter whose version moved (all of them with `force`: inside a captured graph).  The packs are pure HBM traffic (1.3 GB at cfg2) while the
-        first stages of the forward pass are MFMA/LDS bound: they run on the side stream in first-use order and each
-        consumer conv waits for its own parameter's event."""
-        # Staleness: tensor version / address AND the model's weight epoch.  torch's FUSED optimizers (fused=True
-        # Adam/AdamW/SGD: `_fused_adamw_` ...) update parameters WITHOUT bumping `Tensor._version`, so a version check alone
-        # would keep the initial packed weights for a whole training run.  Every backward pass through the engine
-        # therefore starts a new weight epoch (an optimizer step is what normally follows it) and all plans of the model
-        # re-pack on their next forward; pure inference (no backward) keeps its packs.
-        epoch = getattr(self.net, "_weights_epoch", 0)
-        stale = [e for e in self.packs
-                 if force or e.get("epoch") != epoch
-                 or not (e["version"] == e["param"]._version and e.get("ptr") == e["param"].data_ptr())]
+        """re-pack every parameter whose version moved (all of them with `force`: inside a captured graph).  The packs are pure HBM
+        traffic (1.7 GB at cfg2) while the first stages of the forward pass are MFMA/LDS bound: they run on the side stream in
+        first-use order, in a few table launches, and each consumer conv waits for its group's event."""
+        stale = self._packs_stale(force)
         if not stale:
             return
         side = None
         if self.device.type == "cuda" and self.overlap_wgrad:
-            if self._side is None:
-                self._side = side_stream(self.device)
-                self._ws2 = torch.empty(ops.workspace().numel(), dtype=torch.uint8, device=self.device)
+            self._ensure_side()
             side = self._side
-            side.wait_stream(torch.cuda.current_stream())      # the optimizer's writes are on the main stream
+            ops.event_record(self._ev_fork)                    # the optimizer's writes are on the main stream
+            ops.stream_wait(self._ev_fork, side)
         self._pack_entries(stale, side)
 
     def _pack_entries(self, entries, side):
+        """re-pack `entries` (in first-use order) on `side` (or the current stream).  Table launches (rx_pack_multi, 40 tensors
+        each) in GROUPS of ~RX_PACK_GROUP_MB of parameters with one numbered event per group: the first convs of the forward
+        wait for the first (small) group only, the 512-channel stages' packing runs under the stages before them.  Was: one
+        launch + one event per tensor, 66 launches of 17 us on average per cfg2 step."""
+        limit = int(float(os.environ.get("RX_PACK_GROUP_MB", "96")) * (1 << 20))
+        groups, cur, cur_bytes = [], [], 0
         for ent in entries:
-            p = ent["param"]
-            w = p.detach()
-            if w.dtype != torch.float32 or not w.is_contiguous():
-                w = w.float().contiguous()
-            if self.two_d:
-                w = w.unsqueeze(2)
-            ctx = torch.cuda.stream(side) if side is not None else _NullCtx()
-            with ctx:
-                if ent["kind"] == "conv":
-                    ops.pack_conv_weight(w, self.dtype, ent["w_fwd"], ent["w_bwd"], True, ent["w_bwd"] is not None)
-                else:
-                    ops.pack_convT_weight(w, self.dtype, ent["w_fwd"], ent["w_bwd"], True, ent["w_bwd"] is not None)
+            nb = ent["param"].numel() * 4
+            if cur and cur_bytes + nb > limit and len(groups) < 3:     # at most 4 groups: [first ~96 MB] [next] [next] [rest]
+                groups.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(ent)
+            cur_bytes += nb
+        if cur:
+            groups.append(cur)
+        ctx = torch.cuda.stream(side) if side is not None else _NullCtx()
+        with ctx:
+            for gi, grp in enumerate(groups):
+                items = []
+                for ent in grp:
+                    w = ent["param"].detach()
+                    if w.dtype != torch.float32 or not w.is_contiguous():
+                        w = w.float().contiguous()
+                        self._unstable_params = True        # a temporary: its address is not replayable
+                    if self.two_d:
+                        w = w.unsqueeze(2)
+                    items.append((w, 0 if ent["kind"] == "conv" else 1, ent["w_fwd"], ent["w_bwd"]))
+                ops.pack_weights_multi(items, self.dtype)
+                slot = None
                 if side is not None:
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    ent["event"] = ev
-            ent["version"] = p._version
-            ent["ptr"] = p.data_ptr()
-            ent["epoch"] = getattr(self.net, "_weights_epoch", 0)
+                    while len(self._pack_slots) <= gi:
+                        self._pack_slots.append(ops.event_new())
+                    slot = self._pack_slots[gi]
+                    ops.event_record(slot)
+                for ent in grp:
+                    p = ent["param"]
+                    ent["event"], ent["group"] = slot, grp
+                    ent["version"], ent["ptr"] = p._version, p.data_ptr()
+                    ent["epoch"] = getattr(self.net, "_weights_epoch", 0)
 
     def repack(self, entries):
         """re-pack `entries` on the side stream NOW (called from inside a `torch.cuda.stream(side)` block by the streamed
         optimizer step, right after the update of those parameters) and mark them fresh"""
         self._pack_entries(entries, self._side)
+
+    # ---- launch programs -------------------------------------------------------------------------------------
+    def _programs_on(self):
+        return (self.use_programs and not self.use_graphs and self.device.type == "cuda" and ops._PROF is None
+                and not getattr(self, "_unstable_params", False))
+
+    def _streams(self):
+        main = torch.cuda.current_stream()
+        return [main] + ([self._side] if self._side is not None else [])
+
+    def _programmed(self, key, body, segments=None):
+        """run `body` eagerly twice (lazy allocations, workspace growth, first-use attributes), then once more under the
+        library's recorder, and replay the recorded program ever after.  `segments(prog, streams)` (optional) replays it
+        piecewise (the gradient synchroniser's bucket launches sit between segments).  Returns (state, replayed?)."""
+        st = self._pstate.setdefault(key, {"calls": 0})
+        ptrs = self._param_ptrs()
+        if st.get("prog") is not None and st["ptrs"] != ptrs:       # parameters were re-allocated: start over
+            st.clear()
+            st["calls"] = 0
+        if st.get("prog") is not None:
+            streams = self._streams()
+            if segments is not None:
+                segments(st, streams)
+            else:
+                st["prog"].run(streams)
+            return st, True
+        if st["calls"] < 2:
+            st["calls"] += 1
+            st["result"] = body()
+            return st, False
+        prog = ops.Program()
+        self._ws_refs += [ops.workspace(), self._ws2]     # the recorded scratch pointers stay alive with the plan
+        self._marks = []
+        self._recording = prog
+        self._on_side = False
+        prog.begin(self._streams())
+        try:
+            st["result"] = body()
+        finally:
+            self._recording = None
+            prog.end()
+        st["prog"], st["ptrs"], st["marks"] = prog, ptrs, list(self._marks)
+        return st, False
+
+    def _grad_store(self):
+        """one flat fp32 buffer for every parameter gradient, in readiness order: a recorded backward writes the SAME addresses
+        every step.  autograd gets fresh tensor objects over it and normally adopts them as `.grad`; a `.grad` the caller kept
+        (gradient accumulation) is moved out of the way before the next backward overwrites the storage."""
+        if self._gflat is None:
+            offs, n = {}, 0
+            for idx in self.grad_order:
+                if idx not in offs:
+                    offs[idx] = n
+                    n += (self.params[idx].numel() + 63) // 64 * 64
+            self._gflat = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
+            self.bytes_alloc += self._gflat.numel() * 4
+            lo, hi = self._gflat.data_ptr(), self._gflat.data_ptr() + self._gflat.numel() * 4
+            self._gflat_range = (lo, hi)
+            for idx, o in offs.items():
+                p = self.params[idx]
+                self._gviews[idx] = self._gflat[o:o + p.numel()].view(p.shape)
+        lo, hi = self._gflat_range
+        for p in self.params:                      # gradient accumulation: a kept .grad must not alias what we overwrite now
+            gr = p.grad
+            if gr is not None and lo <= gr.data_ptr() < hi:
+                p.grad = gr.clone()
 
     # ---- HIP graph plumbing ---------------------------------------------------------------------------------
     def _graphs_on(self):
@@ -874,16 +1007,27 @@ class Plan:
         st["eager"] = False
         return st
 
-    def _forward_body(self, force_packs):
+    def _forward_pre(self):
+        """host-side work of a forward that is not a library call (never part of a recorded program)"""
         ev = getattr(self.net, "_raw_param_event", None)   # stem / bias / head parameters are read raw by the kernels:
         if ev is not None and ev is not self._raw_seen:     # a streamed optimizer step updates them on the side stream
             torch.cuda.current_stream().wait_event(ev)
             self._raw_seen = ev
+        for g in self._gates:                               # DropPath: this step's per-sample factors (torch RNG)
+            g["scale_now"] = self._draw_path_scale(g)
+
+    def _forward_body(self, force_packs):
         self.refresh_packs(force=force_packs)
         for step in self.fwd:
             step()
         for ent in self.packs:          # parameters of unused branches: never leave a pack in flight
             self._await_pack(ent)
+
+    def _mark_packs_fresh(self):
+        epoch = getattr(self.net, "_weights_epoch", 0)
+        for ent in self.packs:
+            ent["version"], ent["ptr"], ent["event"] = ent["param"]._version, ent["param"].data_ptr(), None
+            ent["epoch"] = epoch
 
     def run_forward(self, x, apply_act):
         if tuple(x.shape) != self.in_shape:
@@ -892,6 +1036,7 @@ class Plan:
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
         self._apply_act = apply_act
+        self._forward_pre()
         if self._graphs_on():
             if self._x_static is None:
                 self._x_static = torch.empty(self.in_shape, dtype=torch.float32, device=self.device)
@@ -902,9 +1047,20 @@ class Plan:
             self._graphed(("f", apply_act), lambda: self._forward_body(force_packs=capturing))
             st = self._gstate[("f", apply_act)]
             if not st["eager"]:                       # the graph re-packed every parameter
-                for ent in self.packs:
-                    ent["version"], ent["ptr"], ent["event"] = ent["param"]._version, ent["param"].data_ptr(), None
-                    ent["epoch"] = getattr(self.net, "_weights_epoch", 0)
+                self._mark_packs_fresh()
+        elif self._programs_on():
+            self._ensure_side()
+            if self._x_static is None:
+                self._x_static = torch.empty(self.in_shape, dtype=torch.float32, device=self.device)
+            self._x_static.copy_(x)                 # the program reads a fixed address
+            self._x = self._x_static.unsqueeze(2) if self.two_d else self._x_static
+            stale = bool(self._packs_stale())
+            dropping = any(g["scale_now"] is not None for g in self._gates)
+            # one program per launch-list VARIANT: with / without the weight re-pack, with / without DropPath factors
+            key = ("f", apply_act, stale, dropping, self.overlap_wgrad)
+            _, replayed = self._programmed(key, lambda: self._forward_body(force_packs=stale))
+            if replayed and stale:
+                self._mark_packs_fresh()
         else:
             self._x = x.unsqueeze(2) if self.two_d else x
             self._forward_body(force_packs=False)
@@ -915,14 +1071,14 @@ class Plan:
         return outs
 
     def _backward_body(self):
-        self._grads = [None] * len(self.params)
-        self._dy_free.clear()       # the previous backward ended with main.wait_stream(side): nothing is still read
-        if self.grad_sync is not None:
-            self.grad_sync.begin(self)
+        self._dy_free.clear()       # the previous backward ended with the side stream joined: nothing is still read
         for step in self.bwd:
             step()
         if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)     # every weight gradient is complete
+            ops.event_record(self._ev_join, self._side)     # every weight gradient is complete
+            ops.stream_wait(self._ev_join)
+
+    def _backward_finish(self):
         grads = self._grads
         if self.grad_sync is not None:
             self.grad_sync.finish()
@@ -931,8 +1087,26 @@ class Plan:
         self._grads = []
         return grads
 
+    def _replay_backward_segments(self, st, streams):
+        """replay a recorded backward with the gradient synchroniser's hooks at the recorded positions: `ready(idx)` right
+        after the command that completed gradient idx, announced from the stream that produced it"""
+        prog, sync, pos = st["prog"], self.grad_sync, 0
+        for cmd, idx, on_side in st["marks"]:
+            if cmd > pos:
+                prog.run(streams, pos, cmd)
+                pos = cmd
+            self._grads[idx] = sync.alloc(idx)
+            if on_side and self._side is not None:
+                with torch.cuda.stream(self._side):
+                    sync.ready(idx)
+            else:
+                sync.ready(idx)
+        prog.run(streams, pos, -1)
+
     def run_backward(self, dlogits: Dict[str, Optional[torch.Tensor]]):
         graphs = self._graphs_on()
+        # programs: every task must take part in the loss (the zero-fill path of an absent task is torch ops, not library calls)
+        programs = (not graphs) and self._programs_on() and all(dlogits.get(k) is not None for k in self.outputs)
         self._dlogits = {}
         for k, g in dlogits.items():
             if g is None:
@@ -940,20 +1114,41 @@ class Plan:
             g = g.detach()
             if g.dtype != torch.float32 or not g.is_contiguous():
                 g = g.float().contiguous()
-            if graphs:
+            if graphs or programs:
                 buf = self._dl_static.get(k)
                 if buf is None or buf.shape != g.shape:
                     buf = self._dl_static[k] = torch.empty_like(g)
                 buf.copy_(g)
                 g = buf
             self._dlogits[k] = g.unsqueeze(2) if self.two_d else g
-        if self.overlap_wgrad and self._side is None and self.device.type == "cuda":
-            self._side = side_stream(self.device)
-            self._ws2 = torch.empty(ops.workspace().numel(), dtype=torch.uint8, device=self.device)
+        self._ensure_side()
         # a backward is what an optimizer step follows: new weight epoch for every plan of this model (see refresh_packs)
         self.net._weights_epoch = getattr(self.net, "_weights_epoch", 0) + 1
+        self._grads = [None] * len(self.params)
+        if programs:
+            sync = self.grad_sync
+            self._use_gstore = sync is None
+            if sync is None:
+                self._grad_store()
+            else:
+                sync.persistent = True          # bucket storage is reused step after step (recorded pointers)
+                sync.begin(self)
+            key = ("b", tuple(sorted(self._dlogits)), id(sync) if sync is not None else 0, self.overlap_wgrad)
+            st, replayed = self._programmed(key, self._backward_body,
+                                            segments=self._replay_backward_segments if sync is not None else None)
+            if replayed and sync is None:
+                for idx in set(self.grad_order):
+                    self._grads[idx] = self._gviews[idx]
+            grads = self._backward_finish()
+            # fresh tensor objects over the persistent storage (autograd adopts a gradient only if nobody else holds it)
+            return [t.detach() if t is not None else None for t in grads]
+        self._use_gstore = False
+        if self.grad_sync is not None:
+            self.grad_sync.persistent = False
+            self.grad_sync.begin(self)
         if not graphs:
-            return self._backward_body()
+            self._backward_body()
+            return self._backward_finish()
         key = ("b", tuple(sorted(self._dlogits)))
         st = self._gstate.get(key)
         if st is not None and st.get("graph") is not None:
@@ -964,7 +1159,11 @@ class Plan:
                 gr = p.grad
                 if gr is not None and gr.data_ptr() in owned:
                     p.grad = gr.clone()
-        st = self._graphed(key, self._backward_body)
+
+        def body():
+            self._backward_body()
+            return self._backward_finish()
+        st = self._graphed(key, body)
         grads = st["result"]
         if st["eager"]:
             return grads

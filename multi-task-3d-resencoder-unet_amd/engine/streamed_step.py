@@ -70,6 +70,7 @@ class StreamedOptimizerStep:
             self._warm = True
             return
         plan = plans[0]
+        plan.use_programs = False       # a recorded forward does not wait for packs that THIS step leaves in flight
         side, main = plan._side, torch.cuda.current_stream()
         group_of = {}
         for g in self.opt.param_groups:

@@ -53,8 +53,10 @@ class EngineAdamW(torch.optim.Optimizer):
             if self._norm_ws is None or self._norm_ws.numel() < need or self._norm_ws.device != grads[0].device:
                 self._norm_ws = torch.empty(int(need), dtype=torch.float32, device=grads[0].device)
             out = torch.empty(2, dtype=torch.float32, device=grads[0].device)
-            check(load().rx_grad_norm_clip(n, VP(*[g.data_ptr() for g in grads]), numel, float(max_norm), _p(self._norm_ws),
-                                           self._norm_ws.numel(), _p(out), stream_ptr()), "rx_grad_norm_clip")
+            from ...engine import ops as _ops
+            _ops.timed_bytes("grad_norm_clip", 4 * sum(g.numel() for g in grads), lambda: check(
+                load().rx_grad_norm_clip(n, VP(*[g.data_ptr() for g in grads]), numel, float(max_norm), _p(self._norm_ws),
+                                         self._norm_ws.numel(), _p(out), stream_ptr()), "rx_grad_norm_clip"))
             self._clip = out[1:2]
             return out[0]
         norms = torch._foreach_norm(grads, norm_type)
@@ -120,11 +122,14 @@ class EngineAdamW(torch.optim.Optimizer):
         for step_no, its in by_step.items():
             n = len(its)
             VP, LP = ctypes.c_void_p * n, ctypes.c_long * n
-            check(load().rx_adamw_flat_multi(n, VP(*[p.data_ptr() for p, _, _ in its]), VP(*[g.data_ptr() for _, g, _ in its]),
-                                             VP(*[st["exp_avg"].data_ptr() for _, _, st in its]),
-                                             VP(*[st["exp_avg_sq"].data_ptr() for _, _, st in its]),
-                                             LP(*[p.numel() for p, _, _ in its]), _p(clip), group["lr"], b1, b2, group["eps"],
-                                             group["weight_decay"], step_no, stream_ptr()), "rx_adamw_flat_multi")
+            from ...engine import ops as _ops
+            # AdamW touches p, g, m, v (read) and p, m, v (write): 28 bytes per parameter
+            _ops.timed_bytes("adamw", 28 * sum(p.numel() for p, _, _ in its), lambda: check(
+                load().rx_adamw_flat_multi(n, VP(*[p.data_ptr() for p, _, _ in its]), VP(*[g.data_ptr() for _, g, _ in its]),
+                                           VP(*[st["exp_avg"].data_ptr() for _, _, st in its]),
+                                           VP(*[st["exp_avg_sq"].data_ptr() for _, _, st in its]),
+                                           LP(*[p.numel() for p, _, _ in its]), _p(clip), group["lr"], b1, b2, group["eps"],
+                                           group["weight_decay"], step_no, stream_ptr()), "rx_adamw_flat_multi"))
 
     # ---- pieces of step() for engine/streamed_step.py: the same update for a SUBSET of the parameters, on the current stream ----
     def take_clip(self):

@@ -77,7 +77,7 @@ def _worker(rank, world, port, cfg, q):
                 backward(r, m)
                 local[(r, m)] = grab()
 
-        # ---- the data-parallel run of THIS rank, three times over (a race would not show on every pass)
+        # ---- the data-parallel run of THIS rank, five times over (a race would not show on every pass)
         sync = GradSync(bucket_bytes=cfg["bucket_bytes"])
         for plan in net._plans.values():
             plan.grad_sync = sync
@@ -104,7 +104,7 @@ def _worker(rank, world, port, cfg, q):
         for bi, b in enumerate(sync._plan_layout(plan0)):      # which bucket each parameter travels in (failure diagnostics)
             for j in b.idxs:
                 bucket_of[pidx[id(plan0.params[j])]] = bi
-        for rep in range(3):
+        for rep in range(5):      # passes 1-2 eager, 3 records the launch program, 4-5 replay it
             for m in range(nmb):
                 sync.require_sync = (m == nmb - 1)
                 backward(rank, m)

@@ -429,3 +429,65 @@ def test_torch_compile_wrapper_trains_and_keeps_reference_checkpoint_keys(Networ
     with torch.no_grad():
         ev = cm(x)
     assert all(v.shape == bare_logits[k].shape for k, v in ev.items())
+
+
+@pytest.mark.parametrize("variant", ["two_heads_bf16", "se_droppath_fp32"])
+def test_launch_program_replay_is_bit_identical_to_eager(NetworkFromConfig, monkeypatch, variant):
+    """launch programs (default on, include/rxunet.h "launch programs"): after two eager passes every forward / backward
+    launch list is recorded by the library while it executes and then replayed from C.  Same launches, same streams,
+    deterministic reductions -> losses, evaluation outputs and parameters after 9 steps must be IDENTICAL to a run with
+    RX_PROGRAMS=0 (one host call per launch).  Covered on purpose: a different input every step (the program reads a static
+    copy), gradient accumulation across replays (a kept .grad is moved off the persistent gradient storage), an evaluation
+    forward between training steps (its own plan and the without-re-pack variant), a task left out of the loss (falls
+    back to the eager list), SqueezeExcite + DropPath (per-step random factors drawn outside the program)."""
+    from golden_cases import _manual, TASKS_2HEAD
+    if variant == "two_heads_bf16":
+        c = CASES["auto16_2head"]
+        patch, tasks, cin, batch, auto, mc, dtype = c["patch"], c["tasks"], c["in_channels"], c["batch"], True, {}, torch.bfloat16
+    else:
+        patch, tasks, cin, batch, auto, dtype = (16, 16, 16), TASKS_2HEAD, 1, 2, False, None
+        mc = _manual(squeeze_excitation=True, stochastic_depth_p=0.3)
+
+    def run(programs):
+        monkeypatch.setenv("RX_PROGRAMS", "1" if programs else "0")
+        mgr = oracle.make_mgr(patch, tasks, cin, batch, auto, mc)
+        torch.manual_seed(4)
+        net = NetworkFromConfig(mgr).cuda()
+        opt = torch.optim.SGD([p for p in net.parameters()], lr=0.05)
+        losses, evals = [], []
+        for step in range(9):
+            x, targets = oracle.synthetic_batch(batch, cin, patch, tasks, 100 + step)
+            x, targets = x.cuda(), {k: v.cuda() for k, v in targets.items()}
+            net.train()
+            with torch.autocast("cuda", dtype=dtype, enabled=dtype is not None):
+                out = net(x)
+            if step == 7:                         # one task outside the loss: unused-head path
+                loss = oracle.train_loss({"sheet": out["sheet"]}, {"sheet": targets["sheet"]}, {"sheet": tasks["sheet"]})
+            else:
+                loss = oracle.train_loss(out, targets, tasks)
+            loss.backward()
+            losses.append(loss.item())
+            if step == 4:
+                continue                          # no optimizer step / zero_grad: step 5 ACCUMULATES into the kept gradients
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            if step in (2, 5, 6):
+                net.eval()
+                with torch.no_grad(), torch.autocast("cuda", dtype=dtype, enabled=dtype is not None):
+                    evals.append({k: v.clone() for k, v in net(x).items()})
+        plans = list(net._plans.values())
+        recorded = [st for plan in plans for st in plan._pstate.values() if st.get("prog") is not None]
+        if programs:
+            assert len(recorded) >= 3 and all(len(st["prog"]) > 10 for st in recorded), "programs were never recorded"
+        else:
+            assert not recorded
+        return losses, evals, {n: p.detach().clone() for n, p in net.named_parameters()}
+
+    l_e, e_e, p_e = run(False)
+    l_p, e_p, p_p = run(True)
+    assert l_e == l_p
+    for a, b in zip(e_e, e_p):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    for n in p_e:
+        assert torch.equal(p_e[n], p_p[n]), n

@@ -503,3 +503,36 @@ def test_instnorm_act_head_fwd_is_the_two_calls(ops, dtype, k, act):
     torch.cuda.synchronize()
     assert torch.equal(o1.t, o2.t)
     assert torch.allclose(l1, l2, rtol=2e-6, atol=2e-6), (l1 - l2).abs().max()     # same products, fp32 sums differ in the last bit
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pack_multi_matches_reference_layouts(ops, dtype):
+    """rx_pack_multi (one table launch per 40 tensors): every packed copy equals the plain permutation of the PyTorch weight
+    -- w_fwd [T][Co][Ci], w_bwd [T][Ci][Co] for Conv3d (Co,Ci,kz,ky,kx) and ConvTranspose3d (Ci,Co,kz,ky,kx) -- bit for bit
+    (a cast to the compute type is the only arithmetic), and equals the single-tensor entry points.  45 tensors: two launches."""
+    g = torch.Generator().manual_seed(3)
+    shapes = [(0, 32, 32, (3, 3, 3)), (0, 64, 32, (3, 3, 3)), (0, 64, 32, (1, 1, 1)), (1, 64, 32, (2, 2, 2)), (1, 128, 64, (1, 2, 2)),
+              (0, 96, 64, (1, 3, 3)), (0, 512, 256, (3, 3, 3)), (1, 512, 512, (2, 2, 2)), (0, 40, 24, (3, 3, 3))] * 5
+    items, refs = [], []
+    for kind, a, b, k in shapes:
+        w = torch.randn((a, b, *k), generator=g).cuda()
+        t = k[0] * k[1] * k[2]
+        co, ci = (a, b) if kind == 0 else (b, a)
+        wf = torch.full((t, co, ci), 7.0, dtype=dtype, device="cuda")
+        wb = torch.full((t, ci, co), 7.0, dtype=dtype, device="cuda")
+        items.append((w, kind, wf, wb))
+        flat = w.reshape(a, b, t)
+        if kind == 0:       # (Co, Ci, T)
+            refs.append((flat.permute(2, 0, 1).to(dtype), flat.permute(2, 1, 0).to(dtype)))
+        else:               # (Ci, Co, T)
+            refs.append((flat.permute(2, 1, 0).to(dtype), flat.permute(2, 0, 1).to(dtype)))
+    ops.pack_weights_multi(items, dtype)
+    for (w, kind, wf, wb), (rf, rb) in zip(items, refs):
+        assert torch.equal(wf, rf.contiguous()) and torch.equal(wb, rb.contiguous()), (kind, tuple(w.shape))
+        one = ops.pack_conv_weight(w, dtype) if kind == 0 else ops.pack_convT_weight(w, dtype)
+        assert torch.equal(one[0], wf) and torch.equal(one[1], wb)
+    # forward-only plans pack no bwd copy
+    w, kind, wf, wb = items[0]
+    wf2 = torch.zeros_like(wf)
+    ops.pack_weights_multi([(w, kind, wf2, None)], dtype)
+    assert torch.equal(wf2, wf)
