@@ -182,9 +182,10 @@ def through_trainer(workload, batch, dtype, warmup, steps):
             "tr_setup": {"model_name": f"bench_{workload}", "autoconfigure": w["autoconfigure"], "tr_val_split": 0.95,
                          "ckpt_out_base": os.path.join(tmp, "ckpt"), "tensorboard_log_dir": os.path.join(tmp, "tb")},
             "tr_config": {"optimizer": "AdamW", "initial_lr": 1e-3, "weight_decay": 0, "gradient_accumulation": 1,
-                          "num_dataloader_workers": min(8, host_threads()), "patch_size": list(w["patch"]), "batch_size": batch,
+                          "num_dataloader_workers": int(os.environ.get("RX_BENCH_WORKERS", "0")), "patch_size": list(w["patch"]), "batch_size": batch,
                           "max_steps_per_epoch": n_steps, "max_val_steps_per_epoch": 1, "max_epoch": 2,
-                          "amp_dtype": dtype, "engine_optimizer": True},
+                          "amp_dtype": dtype, "engine_optimizer": True,
+                          "compile": os.environ.get("RX_BENCH_COMPILE", "1") != "0"},
             "model_config": dict(w["model_config"]),
             "dataset_config": {"synthetic": True, "synthetic_length": int(n_steps * batch / 0.95) + 2 * batch,
                                "in_channels": w["in_channels"], "targets": w["tasks"]},

@@ -38,6 +38,49 @@ from .training.optim import clip_and_step
 _AMP = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}
 
 
+class PinnedRingCollate:
+    """`collate_fn` of the in-process loader (num_workers == 0): stacks the items of a batch straight into PERSISTENT pinned host
+    buffers (a ring of `depth` batches) instead of `default_collate` + `pin_memory=True`.  At 128^3 the default path costs ~27 ms
+    of host time per batch on the GPU box (a fresh 16 MB tensor per key: page faults on first touch, then a second copy into a
+    freshly pinned one) -- more than the 18 ms the GPU needs for the step.  A slot is reused only after the H2D copies that
+    read it have completed (`copied()` records an event on the copying stream)."""
+
+    def __init__(self, depth=4):
+        self.depth = depth
+        self.slots = [None] * depth
+        self.events = [None] * depth
+        self.turn = 0
+        self.last = None
+
+    def __call__(self, items):
+        slot = self.turn % self.depth
+        self.turn += 1
+        ev = self.events[slot]
+        if ev is not None:
+            ev.synchronize()
+            self.events[slot] = None
+        bufs = self.slots[slot] or {}
+        out = {}
+        for k, first in items[0].items():
+            first = torch.as_tensor(first)
+            shape = (len(items), *first.shape)
+            b = bufs.get(k)
+            if b is None or tuple(b.shape) != shape or b.dtype != first.dtype:
+                b = torch.empty(shape, dtype=first.dtype, pin_memory=torch.cuda.is_available())
+            torch.stack([torch.as_tensor(it[k]) for it in items], 0, out=b)
+            out[k] = b
+        self.slots[slot] = out
+        self.last = slot
+        return out
+
+    def copied(self):
+        """call after the `.to(device, non_blocking=True)` copies of the batch returned last were enqueued"""
+        if self.last is not None and torch.cuda.is_available():
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events[self.last] = ev
+
+
 class BaseTrainer:
     def __init__(self, config_file: str, verbose: bool = True, debug_dataloader: bool = False):
         self.mgr = ConfigManager(config_file, verbose=verbose)
@@ -105,9 +148,14 @@ class BaseTrainer:
                 raise ValueError(f"{len(tr)} training patches cannot be split over {self.world} ranks")
             tr = tr[:per_rank * self.world][self.rank::self.world]
         workers = self.mgr.train_num_dataloader_workers
+        # in-process loading: batches are assembled directly in persistent pinned buffers (PinnedRingCollate); with worker
+        # processes the default collate + the loader's pin-memory thread, workers kept alive across epochs
+        ring = PinnedRingCollate() if workers == 0 else None
+        extra = dict(collate_fn=ring, pin_memory=False) if ring is not None else dict(pin_memory=True, persistent_workers=True)
         train = DataLoader(dataset, batch_size=self.mgr.train_batch_size, sampler=SubsetRandomSampler(tr),
-                           pin_memory=True, num_workers=workers)
-        val = DataLoader(dataset, batch_size=1, sampler=SubsetRandomSampler(va), pin_memory=True, num_workers=workers)
+                           num_workers=workers, **extra)
+        val = DataLoader(dataset, batch_size=1, sampler=SubsetRandomSampler(va), pin_memory=True,
+                         num_workers=workers, **({"persistent_workers": True} if workers else {}))
         return train, val
 
     # ---- helpers ----------------------------------------------------------------------------------
@@ -184,6 +232,9 @@ class BaseTrainer:
         def forward_loss(batch, train_mode):
             x = batch["image"].to(device, dtype=torch.float32, non_blocking=True)
             targets = {k: v.to(device, dtype=torch.float32, non_blocking=True) for k, v in batch.items() if k != "image"}
+            ring = getattr(train_loader, "collate_fn", None)
+            if train_mode and isinstance(ring, PinnedRingCollate):
+                ring.copied()               # the pinned slot may be refilled once these copies are done
             with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
                 out = model(x)
                 if sync is not None:
