@@ -177,6 +177,7 @@ def through_trainer(workload, batch, dtype, warmup, steps):
     from mt3d_amd.train import BaseTrainer
     w = WORKLOADS[workload]
     n_steps = max(warmup, 1) + steps
+    torch.set_num_threads(host_threads())      # the box's CPU share, not the host's core count (oversubscribed copies crawl)
     with tempfile.TemporaryDirectory() as tmp:
         cfg = {
             "tr_setup": {"model_name": f"bench_{workload}", "autoconfigure": w["autoconfigure"], "tr_val_split": 0.95,

@@ -182,7 +182,7 @@ int rx_instnorm_act_pool_fwd(rx_dtype dt, const rx_act* y, const float* stats, c
 int rx_avgpool_bwd(rx_dtype dt, const rx_act* dy, const rx_act* dx, const int32_t stride[3], int accumulate,
                    void* stream);
 
-/* ---- stem: first Conv3d on the NCDHW fp32 image, Cin <= 4 (encoder.py:84) ---------------- */
+/* ---- stem: first Conv3d on the NCDHW fp32 image, Cin <= 8 (encoder.py:84; MFMA kernels for Cin <= 4) ---- */
 int rx_stem_conv_fwd(rx_dtype dt, const float* x_ncdhw, int n, int cin, int z, int y, int x, const float* w,
                      const float* bias, const rx_act* out, const int32_t kernel[3], void* stream);
 size_t rx_stem_conv_bwd_weight_workspace(int cin, int cout, int taps);
@@ -190,7 +190,7 @@ int rx_stem_conv_bwd_weight(rx_dtype dt, const float* x_ncdhw, int n, int cin, i
                             const rx_act* dy, float* dw, const int32_t kernel[3], void* ws, size_t ws_bytes,
                             void* stream);
 
-/* ---- task head: Conv3d 1x1x1 with bias to K <= 8 channels, NCDHW fp32 logits, optional
+/* ---- task head: Conv3d 1x1x1 with bias to K <= 16 channels, NCDHW fp32 logits, optional
  *      eval-mode activation (decoder.py:131,151-152; build_network_from_config.py:320-323) ---- */
 int rx_head_fwd(rx_dtype dt, const rx_act* x, const float* w, const float* b, int k, float* out_ncdhw,
                 int act, void* stream);

@@ -999,9 +999,9 @@ extern "C" int rx_avgpool_bwd(rx_dtype dt, const rx_act* dy, const rx_act* dx, c
   return RX_OK;
 }
 
-// ---- task head: 1x1x1 conv with bias to K <= 8 channels -------------------------------------
-#define RX_HEAD_MAXK 8
-template <typename T>
+// ---- task head: 1x1x1 conv with bias to K <= 16 channels (accumulator arrays sized 8 or 16: K <= 8 keeps the lean kernel) ---
+#define RX_HEAD_MAXK 16
+template <typename T, int MAXK>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, int ldx, long sx, const float* __restrict__ w,
                                                        const float* __restrict__ b, int K, float* __restrict__ out, int V, int C, int act) {
   constexpr int P = Elem<T>::PER16;
@@ -1011,14 +1011,14 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
   const int n = blockIdx.y;
   const int CV = C / P;
   for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long)gridDim.x * 256) {
-    float acc[RX_HEAD_MAXK];
+    float acc[MAXK];
 #pragma unroll
-    for (int k = 0; k < RX_HEAD_MAXK; ++k) acc[k] = k < K ? b[k] : 0.f;
+    for (int k = 0; k < MAXK; ++k) acc[k] = k < K ? b[k] : 0.f;
     const T* xp = x + n * sx + v * ldx;
     for (int cv = 0; cv < CV; ++cv) {
       Vec16<T> t = ld16(xp + cv * P);
 #pragma unroll
-      for (int k = 0; k < RX_HEAD_MAXK; ++k)
+      for (int k = 0; k < MAXK; ++k)
         if (k < K) {
 #pragma unroll
           for (int j = 0; j < P; ++j) acc[k] += Elem<T>::to_f(t.v[j]) * sw[k * C + cv * P + j];
@@ -1026,23 +1026,23 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
     }
     if (act == RX_ACT_SIGMOID) {
 #pragma unroll
-      for (int k = 0; k < RX_HEAD_MAXK; ++k) acc[k] = 1.f / (1.f + expf(-acc[k]));
+      for (int k = 0; k < MAXK; ++k) acc[k] = 1.f / (1.f + expf(-acc[k]));
     } else if (act == RX_ACT_SOFTMAX) {
       float m = -INFINITY, s = 0.f;
 #pragma unroll
-      for (int k = 0; k < RX_HEAD_MAXK; ++k)
+      for (int k = 0; k < MAXK; ++k)
         if (k < K) m = fmaxf(m, acc[k]);
 #pragma unroll
-      for (int k = 0; k < RX_HEAD_MAXK; ++k)
+      for (int k = 0; k < MAXK; ++k)
         if (k < K) {
           acc[k] = expf(acc[k] - m);
           s += acc[k];
         }
 #pragma unroll
-      for (int k = 0; k < RX_HEAD_MAXK; ++k) acc[k] = acc[k] / s;
+      for (int k = 0; k < MAXK; ++k) acc[k] = acc[k] / s;
     }
 #pragma unroll
-    for (int k = 0; k < RX_HEAD_MAXK; ++k)
+    for (int k = 0; k < MAXK; ++k)
       if (k < K) out[((size_t)n * K + k) * V + v] = acc[k];
   }
 }
@@ -1058,15 +1058,19 @@ extern "C" int rx_head_fwd(rx_dtype dt, const rx_act* x, const float* w, const f
   hipStream_t st = (hipStream_t)stream;
   RX_DISPATCH_DTYPE(dt, T, {
     int G = (int)((V + 255) / 256 > 4096 ? 4096 : (V + 255) / 256);
-    hipLaunchKernelGGL((head_fwd_kernel<T>), dim3(G, x->n), dim3(256), (size_t)k * x->c * sizeof(float), st, (const T*)x->ptr, x->ld,
-                       V * x->ld, w, b, k, out_ncdhw, (int)V, x->c, act);
+    if (k <= 8)
+      hipLaunchKernelGGL((head_fwd_kernel<T, 8>), dim3(G, x->n), dim3(256), (size_t)k * x->c * sizeof(float), st, (const T*)x->ptr, x->ld,
+                         V * x->ld, w, b, k, out_ncdhw, (int)V, x->c, act);
+    else
+      hipLaunchKernelGGL((head_fwd_kernel<T, 16>), dim3(G, x->n), dim3(256), (size_t)k * x->c * sizeof(float), st, (const T*)x->ptr, x->ld,
+                         V * x->ld, w, b, k, out_ncdhw, (int)V, x->c, act);
   });
   RX_CHECK_LAUNCH("rx_head_fwd");
   return RX_OK;
 }
 
 // backward: dx[v][c] = sum_k dout[k][v] w[k][c]; dw[k][c] = sum_v dout[k][v] x[v][c]; db[k] = sum_v dout[k][v]
-template <typename T>
+template <typename T, int MAXK>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ x, int ldx, long sx,
                                                        const float* __restrict__ w, int K, T* __restrict__ dx, int lddx, long sdx, int V,
                                                        int C, int chunk_vox, float* __restrict__ partial /*[N][nch][K+1][C]*/) {
@@ -1080,10 +1084,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   __syncthreads();
   const int tid = threadIdx.x, n = blockIdx.y, chunk = blockIdx.x;
   const int vl = tid / CV, cv = tid - vl * CV;
-  float aw[RX_HEAD_MAXK][P];
-  float ab[RX_HEAD_MAXK];
+  float aw[MAXK][P];
+  float ab[MAXK];
 #pragma unroll
-  for (int k = 0; k < RX_HEAD_MAXK; ++k) {
+  for (int k = 0; k < MAXK; ++k) {
     ab[k] = 0.f;
 #pragma unroll
     for (int j = 0; j < P; ++j) aw[k][j] = 0.f;
@@ -1096,7 +1100,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 #pragma unroll
       for (int j = 0; j < P; ++j) d[j] = 0.f;
 #pragma unroll
-      for (int k = 0; k < RX_HEAD_MAXK; ++k)
+      for (int k = 0; k < MAXK; ++k)
         if (k < K) {
           float gk = dout[((size_t)n * K + k) * V + v];
           ab[k] += gk;
@@ -1162,8 +1166,16 @@ extern "C" int rx_head_bwd(rx_dtype dt, const float* dout_ncdhw, const rx_act* x
     float* partial = (float*)ws;
     float* fin = partial + (size_t)N * p.nchunks * (k + 1) * C;
     size_t lds = ((size_t)k * C + (size_t)(k + 1) * VP * C) * sizeof(float);
-    hipLaunchKernelGGL((head_bwd_kernel<T>), dim3(p.nchunks, N), dim3(256), lds, st, dout_ncdhw, (const T*)x->ptr, x->ld, V * x->ld, w, k,
-                       dx ? (T*)dx->ptr : (T*)nullptr, dx ? dx->ld : 0, dx ? V * dx->ld : 0L, (int)V, C, p.chunk_vox, partial);
+    if (lds > 160 * 1024) RX_FAIL(RX_EUNSUPPORTED, "rx_head_bwd: K = %d needs %zu bytes of LDS", k, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<T, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<T, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (k <= 8) {
+      hipLaunchKernelGGL((head_bwd_kernel<T, 8>), dim3(p.nchunks, N), dim3(256), lds, st, dout_ncdhw, (const T*)x->ptr, x->ld, V * x->ld, w, k,
+                         dx ? (T*)dx->ptr : (T*)nullptr, dx ? dx->ld : 0, dx ? V * dx->ld : 0L, (int)V, C, p.chunk_vox, partial);
+    } else {
+      hipLaunchKernelGGL((head_bwd_kernel<T, 16>), dim3(p.nchunks, N), dim3(256), lds, st, dout_ncdhw, (const T*)x->ptr, x->ld, V * x->ld, w, k,
+                         dx ? (T*)dx->ptr : (T*)nullptr, dx ? dx->ld : 0, dx ? V * dx->ld : 0L, (int)V, C, p.chunk_vox, partial);
+    }
     hipLaunchKernelGGL(colreduce_finalize, dim3(((k + 1) * C + 3) / 4), dim3(256), 0, st, (const float*)partial, N, p.nchunks, k + 1,
                        C, (double)V, 0.f, (int)FIN_SUM_OVER_N, fin);
     (void)hipMemcpyAsync(dw, fin, (size_t)k * C * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -1418,7 +1430,7 @@ extern "C" int rx_instnorm_act_bwd_head(rx_dtype dt, const float* dout_ncdhw, in
   return RX_OK;
 }
 
-// ---- stem convolution on the NCDHW fp32 image (Cin <= 4) ------------------------------------
+// ---- stem convolution on the NCDHW fp32 image (Cin <= 8; the MFMA variants of rx_stem_wgrad.hip take Cin <= 4) -----------
 // thread -> (voxel, vector of P output channels); weights in LDS as [tap*Cin][Cout]
 template <typename T>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, int Cin, int Z, int Y, int X, const float* __restrict__ w,
@@ -1542,7 +1554,7 @@ extern "C" int rx_stem_conv_fwd(rx_dtype dt, const float* x_ncdhw, int n, int ci
   int rc;
   if ((rc = check_vec_channels(out, dt, "rx_stem_conv_fwd(out)"))) return rc;
   if ((rc = check_kernel13(kernel, "rx_stem_conv_fwd"))) return rc;
-  if (!x_ncdhw || !w || cin < 1 || cin > 4) RX_FAIL(RX_EUNSUPPORTED, "rx_stem_conv_fwd: 1 <= Cin <= 4");
+  if (!x_ncdhw || !w || cin < 1 || cin > 8) RX_FAIL(RX_EUNSUPPORTED, "rx_stem_conv_fwd: 1 <= Cin <= 8");
   if (out->n != n || out->z != z || out->y != y || out->x != x) RX_FAIL(RX_EINVAL, "rx_stem_conv_fwd: geometry mismatch");
   hipStream_t st = (hipStream_t)stream;
   const int TT = kernel[0] * kernel[1] * kernel[2];
@@ -1681,7 +1693,7 @@ extern "C" int rx_stem_conv_bwd_weight(rx_dtype dt, const float* x_ncdhw, int n,
   int rc;
   if ((rc = check_vec_channels(dy, dt, "rx_stem_conv_bwd_weight(dy)"))) return rc;
   if ((rc = check_kernel13(kernel, "rx_stem_conv_bwd_weight"))) return rc;
-  if (!x_ncdhw || !dw || !ws || cin < 1 || cin > 4) RX_FAIL(RX_EUNSUPPORTED, "rx_stem_conv_bwd_weight: 1 <= Cin <= 4");
+  if (!x_ncdhw || !dw || !ws || cin < 1 || cin > 8) RX_FAIL(RX_EUNSUPPORTED, "rx_stem_conv_bwd_weight: 1 <= Cin <= 8");
   const int Co = dy->c;
   if (Co > 64 || Co % 4 || 64 % (Co / 4)) RX_FAIL(RX_EUNSUPPORTED, "rx_stem_conv_bwd_weight: Cout must be 4,8,16,32 or 64 (got %d)", Co);
   if (dy->n != n || dy->z != z || dy->y != y || dy->x != x) RX_FAIL(RX_EINVAL, "rx_stem_conv_bwd_weight: geometry mismatch");

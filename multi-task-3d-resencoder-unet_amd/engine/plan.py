@@ -257,8 +257,8 @@ class Plan:
         widx = self._param(conv.weight)
         bidx = self._param(conv.bias) if conv.bias is not None else None
         if first_of_net:
-            if cin > 4 or any(s != 1 for s in stride):
-                raise UnsupportedConfig("the first convolution reads the NCDHW image: needs in_channels <= 4, stride 1")
+            if cin > 8 or any(s != 1 for s in stride):
+                raise UnsupportedConfig("the first convolution reads the NCDHW image: needs in_channels <= 8, stride 1")
             self._chk_channels(cout)
             tape.append(Rec("stem", dict(y=y, w=conv.weight, b=conv.bias, widx=widx, bidx=bidx, kernel=kernel)))
         else:
@@ -434,8 +434,8 @@ class Plan:
                 low = h
             head = dec.seg_layers[-1]
             k = head.out_channels
-            if k > 8:
-                raise UnsupportedConfig("task heads with more than 8 channels have no HIP kernel yet")
+            if k > 16:
+                raise UnsupportedConfig("task heads with more than 16 channels have no HIP kernel yet")
             out = torch.empty((self.B, k, *low.act.dims[1:]), dtype=torch.float32, device=self.device)
             self.outputs[name] = out
             act_mod = net.task_activations[name] if name in net.task_activations else None
@@ -594,6 +594,8 @@ class Plan:
             P._grads[idx] = g
             return g
 
+        skip = set(filter(None, os.environ.get("RX_SKIP", "").split(",")))     # TIMING ABLATIONS ONLY (wrong results)
+
         def done(idx):
             if P._recording is not None:        # while a program is recorded: where in the command list the gradient is complete
                 P._marks.append((len(P._recording), idx, P._on_side))
@@ -727,6 +729,10 @@ class Plan:
                         elif a.get("m12_valid"):      # the two means came out of the backward-data kernel that completed gout
                             a["m12_valid"] = False
                             ops.instnorm_act_bwd_apply(gout, a["y"].act, a["stats"], mask_out, dy, a["m12"], a["slope"], gres, acc)
+                        elif "inbwd_reduce" in skip and a["y"].act.voxels > 512:
+                            if "m12x" not in a:
+                                a["m12x"] = torch.zeros((self.B, a["y"].act.c, 2), dtype=torch.float32, device=self.device)
+                            ops.instnorm_act_bwd_apply(gout, a["y"].act, a["stats"], mask_out, dy, a["m12x"], a["slope"], gres, acc)
                         else:
                             ops.instnorm_act_bwd(gout, a["y"].act, a["stats"], mask_out, dy, a["slope"], gres, acc)
                     b.append(istep)
@@ -739,7 +745,9 @@ class Plan:
                         db = new_grad(a["bidx"]) if a["bidx"] is not None else None
 
                         def launches(ws):
-                            if kind == "stem":
+                            if "wgrad" in skip and kind != "stem":
+                                pass
+                            elif kind == "stem":
                                 ops.stem_conv_bwd_weight(P._x, dy, dw, a["kernel"], ws)
                             else:
                                 ops.conv3d_bwd_weight(a["x"].act, dy, dw, a["kernel"], a["stride"], ws)
@@ -761,6 +769,8 @@ class Plan:
                         wrote(x, "conv", bsinfo)
 
                         def dstep(a=a, dy=dy, gx=gx, acc=acc, bsinfo=bsinfo):
+                            if "dgrad" in skip:
+                                return
                             ia = bsinfo["inact"]
                             if ia is None:
                                 ops.conv3d_bwd_data(dy, a["pk"]["w_bwd"], gx, a["kernel"], a["stride"], acc)

@@ -67,7 +67,8 @@ class PinnedRingCollate:
             b = bufs.get(k)
             if b is None or tuple(b.shape) != shape or b.dtype != first.dtype:
                 b = torch.empty(shape, dtype=first.dtype, pin_memory=torch.cuda.is_available())
-            torch.stack([torch.as_tensor(it[k]) for it in items], 0, out=b)
+            for i, it in enumerate(items):          # plain memcpy per item (torch.stack(out=pinned) ran at 1.6 GB/s on the GPU box)
+                b[i].copy_(torch.as_tensor(it[k]))
             out[k] = b
         self.slots[slot] = out
         self.last = slot

@@ -12,4 +12,4 @@ pr.enable()
 r = bench.through_trainer("cfg2", 2, "bf16", 3, 20)
 pr.disable()
 print(r)
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr).sort_stats("tottime").print_stats(30)

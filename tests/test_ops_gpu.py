@@ -232,7 +232,7 @@ def test_avgpool(ops, dtype, s):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cin,k", [(1, (3, 3, 3)), (2, (3, 3, 3)), (1, (1, 3, 3))])
+@pytest.mark.parametrize("cin,k", [(1, (3, 3, 3)), (2, (3, 3, 3)), (1, (1, 3, 3)), (4, (3, 3, 3)), (5, (3, 3, 3)), (8, (3, 3, 3))])   # > 4: VALU kernels
 def test_stem(ops, dtype, cin, k):
     n, co, dims = 2, 32, (6, 9, 10)
     x = rnd((n, cin, *dims), torch.float32, 14)
@@ -253,7 +253,7 @@ def test_stem(ops, dtype, cin, k):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("k", [1, 3])
+@pytest.mark.parametrize("k", [1, 3, 8, 9, 16])        # K <= 8: lean kernel; 9..16: the 16-accumulator instantiation
 def test_head(ops, dtype, k):
     from mt3d_amd.engine import lib
     n, c, dims = 2, 32, (6, 7, 8)

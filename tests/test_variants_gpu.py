@@ -88,10 +88,10 @@ def test_unsupported_configs_fail_loudly(NetworkFromConfig):
     net = NetworkFromConfig(mgr).cuda()
     with pytest.raises(UnsupportedConfig):
         net(torch.zeros(1, 1, 16, 16, 16, device="cuda"))
-    mgr = oracle.make_mgr((16, 16, 16), ONE, 8, 1, True, {})
+    mgr = oracle.make_mgr((16, 16, 16), ONE, 9, 1, True, {})
     net = NetworkFromConfig(mgr).cuda()
     with pytest.raises(UnsupportedConfig):
-        net(torch.zeros(1, 8, 16, 16, 16, device="cuda"))
+        net(torch.zeros(1, 9, 16, 16, 16, device="cuda"))
 
 
 def test_droppath_training_and_eval(NetworkFromConfig):
@@ -152,3 +152,25 @@ def test_droppath_training_and_eval(NetworkFromConfig):
         e_r, e_n = ref(x), net(x.cuda())
     for k in e_r:
         assert rel_l2(e_n[k].cpu(), e_r[k]) < 2e-4
+
+
+def test_widened_configs_six_inputs_twelve_class_head(NetworkFromConfig):
+    """round 2 widening: in_channels up to 8 (the stem's VALU kernels above 4) and task heads up to 16
+    channels (softmax over 12 classes here), against the oracle in fp32 mode.  The 12-channel BCE-Dice loss takes torch's
+    path (the HIP loss kernels cover C <= 8)."""
+    tasks = {"seg": {"channels": 12, "activation": "softmax", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
+    ref, net, o_r, o_n, l_r, l_n = _run(NetworkFromConfig, (16, 16, 16), 6, tasks, manual(), batch=2, seed=11, data_seed=5)
+    assert rel_l2(o_n["seg"].cpu(), o_r["seg"].detach()) < 2e-4
+    assert torch.equal(o_n["seg"].cpu().argmax(1), o_r["seg"].argmax(1))
+    assert abs(l_r.item() - l_n.item()) < 1e-4
+    pr, pn = dict(ref.named_parameters()), dict(net.named_parameters())
+    for n in pr:
+        assert (pr[n].grad is None) == (pn[n].grad is None), n
+        if pr[n].grad is not None and pr[n].grad.norm() > 1e-6:
+            # (data seed 5 has mask margin for this net: oracle fp32 vs fp64 2.5e-6)
+            assert rel_l2(pn[n].grad.cpu(), pr[n].grad) < 1e-3, (n, rel_l2(pn[n].grad.cpu(), pr[n].grad))
+    ref.eval(); net.eval()
+    x, _ = oracle.synthetic_batch(2, 6, (16, 16, 16), tasks, 5)
+    with torch.no_grad():
+        e_r, e_n = ref(x), net(x.cuda())
+    assert rel_l2(e_n["seg"].cpu(), e_r["seg"]) < 2e-4
