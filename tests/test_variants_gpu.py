@@ -159,7 +159,7 @@ def test_widened_configs_six_inputs_twelve_class_head(NetworkFromConfig):
     channels (softmax over 12 classes here), against the oracle in fp32 mode.  The 12-channel BCE-Dice loss takes torch's
     path (the HIP loss kernels cover C <= 8)."""
     tasks = {"seg": {"channels": 12, "activation": "softmax", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
-    ref, net, o_r, o_n, l_r, l_n = _run(NetworkFromConfig, (16, 16, 16), 6, tasks, manual(), batch=2, seed=11, data_seed=5)
+    ref, net, o_r, o_n, l_r, l_n = _run(NetworkFromConfig, (16, 16, 16), 6, tasks, manual(), batch=2, seed=11, data_seed=1)
     assert rel_l2(o_n["seg"].cpu(), o_r["seg"].detach()) < 2e-4
     assert torch.equal(o_n["seg"].cpu().argmax(1), o_r["seg"].argmax(1))
     assert abs(l_r.item() - l_n.item()) < 1e-4
@@ -167,10 +167,11 @@ def test_widened_configs_six_inputs_twelve_class_head(NetworkFromConfig):
     for n in pr:
         assert (pr[n].grad is None) == (pn[n].grad is None), n
         if pr[n].grad is not None and pr[n].grad.norm() > 1e-6:
-            # (data seed 5 has mask margin for this net: oracle fp32 vs fp64 2.5e-6)
+            # (data seed 1 has mask margin for this net on the CPU -- oracle fp32 vs fp64 2.5e-6 -- and on the engine, 1.8e-6
+            # against the fp64 oracle: scripts/seed_margin_gpu.py widened; seed 5 flips one mask in the engine's summation order)
             assert rel_l2(pn[n].grad.cpu(), pr[n].grad) < 1e-3, (n, rel_l2(pn[n].grad.cpu(), pr[n].grad))
     ref.eval(); net.eval()
-    x, _ = oracle.synthetic_batch(2, 6, (16, 16, 16), tasks, 5)
+    x, _ = oracle.synthetic_batch(2, 6, (16, 16, 16), tasks, 1)
     with torch.no_grad():
         e_r, e_n = ref(x), net(x.cuda())
     assert rel_l2(e_n["seg"].cpu(), e_r["seg"]) < 2e-4
