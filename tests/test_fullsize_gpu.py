@@ -108,3 +108,90 @@ def test_cfg2_one_optimizer_step_reduces_the_loss(net):
         opt.step()
         losses.append(l.item())
     assert losses[-1] < losses[0], losses
+
+
+# ---- BASELINE configs[2] and configs[4] at FULL size (exercised on the HIP path only at reduced size) ----------------
+FULL = {
+    # cfg3: cfg2 + a 3-channel normals regression head (second decoder), 128^3, batch 1, bf16
+    "cfg3": dict(patch=(128, 128, 128), cin=1, autoconf=True, mc={}, dtype=torch.bfloat16, lin_tol=1.2e-1,   # two decoders feed every skip: more bf16-rounded hops than cfg2
+                 tasks={"sheet": {"channels": 1, "activation": "none", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}},
+                        "normals": {"channels": 3, "activation": "none", "loss_fn": "MaskedCosineLoss"}}),
+    # cfg5: manual 6-stage topology capped at 320 features, 2 input channels, 160^3 (bottleneck 5^3), batch 1, fp16
+    # (logit gradients of order 1 here: at 1e-3 the activation gradients fall into fp16's subnormal range and the backward stops being
+    # linear -- the reason the reference runs fp16 under a GradScaler, train.py:94-97,224)
+    "cfg5": dict(patch=(160, 160, 160), cin=2, autoconf=False, dtype=torch.float16, lin_tol=1.5e-2, gscale=1.0,
+                 mc={"basic_encoder_block": "BasicBlockD", "basic_decoder_block": "ConvBlock", "bottleneck_block": "BasicBlockD",
+                     "features_per_stage": [32, 64, 128, 256, 320, 320], "num_stages": 6, "n_blocks_per_stage": [1, 3, 4, 6, 6, 6],
+                     "kernel_sizes": [3] * 6, "n_conv_per_stage_decoder": [1] * 5, "strides": [1, 2, 2, 2, 2, 2]},
+                 tasks={"sheet": {"channels": 1, "activation": "none", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_size_multi_head_and_320cap_configs(name):
+    """determinism (bit-identical logits and gradients over two runs, launch-program replays included), linearity of the backward
+    in the logit gradients, finite gradients everywhere, unused deep-supervision heads gradient-less, and three optimizer steps
+    that reduce the task loss -- at the sizes BASELINE.json names, where the CPU oracle would take minutes."""
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
+    from mt3d_amd.training.losses.losses import LOSS_FN_MAP
+    c = FULL[name]
+    mgr = oracle.make_mgr(c["patch"], c["tasks"], c["cin"], 1, c["autoconf"], c["mc"])
+    torch.manual_seed(0)
+    net = NetworkFromConfig(mgr).cuda()
+    net.compute_dtype = c["dtype"]
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.rand((1, c["cin"], *c["patch"]), device="cuda", generator=gen)
+    shapes = {k: (1, v["channels"], *c["patch"]) for k, v in c["tasks"].items()}
+
+    def run(gs):
+        net.zero_grad(set_to_none=True)
+        out = net(x)
+        torch.autograd.backward([out[k] for k in gs], [gs[k] for k in gs])
+        return ({k: v.detach().clone() for k, v in out.items()},
+                {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+
+    gs = c.get("gscale", 1e-3)
+    g1 = {k: torch.randn(s, device="cuda", generator=gen) * gs for k, s in shapes.items()}
+    g2 = {k: torch.randn(s, device="cuda", generator=gen) * gs for k, s in shapes.items()}
+    o1, a = run(g1)
+    for _ in range(3):                       # passes 3 and 4 are the recorded / replayed launch programs
+        o1b, a2 = run(g1)
+        for k in o1:
+            assert torch.equal(o1[k], o1b[k]), k
+        for n in a:
+            assert torch.equal(a[n], a2[n]), f"non-deterministic gradient: {n}"
+    for n in a:
+        assert torch.isfinite(a[n]).all(), n
+    unused = [n for n, _ in net.named_parameters() if n not in a]
+    assert unused and all(".seg_layers." in n for n in unused)
+    _, b = run(g2)
+    _, s12 = run({k: g1[k] + g2[k] for k in g1})
+    for n in a:
+        ref = a[n].double() + b[n].double()
+        if ref.norm() < 1e-9:
+            continue
+        err = ((s12[n].double() - ref).norm() / ref.norm()).item()
+        assert err < c["lin_tol"], (n, err)
+    # a short optimisation on one synthetic batch reduces the loss
+    seg = (torch.rand((1, 1, *c["patch"]), device="cuda", generator=gen) > 0.8).float()
+    targets = {}
+    for k, info in c["tasks"].items():
+        if info["loss_fn"] == "MaskedCosineLoss":
+            v = torch.randn((1, info["channels"], *c["patch"]), device="cuda", generator=gen)
+            targets[k] = torch.nn.functional.normalize(v, dim=1) * seg
+        else:
+            targets[k] = seg
+    fns = {k: LOSS_FN_MAP[info["loss_fn"]](**info.get("loss_kwargs", {})) for k, info in c["tasks"].items()}
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        out = net(x)
+        loss = sum(fns[k](out[k], targets[k]) for k in fns)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0], losses
+    del net
+    torch.cuda.empty_cache()
