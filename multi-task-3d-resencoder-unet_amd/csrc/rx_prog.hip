@@ -137,7 +137,7 @@ extern "C" int rx_prog_run(rx_prog* p, int first, int last, void* const* streams
 }
 
 // ---- numbered events: cross-stream ordering that can be recorded -----------------------------------------------------
-#define RX_MAX_EVENTS 8192
+#define RX_MAX_EVENTS 65536      // slots are never recycled: ~60 per plan (events are created on first use)
 static hipEvent_t g_events[RX_MAX_EVENTS];
 static bool g_event_made[RX_MAX_EVENTS];
 static int g_event_next = 0;

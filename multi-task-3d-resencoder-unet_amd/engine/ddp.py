@@ -29,11 +29,12 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("idxs", "offsets", "numel", "flat", "pending", "work", "streams", "carry")
+    __slots__ = ("idxs", "offsets", "numel", "flat", "pflat", "pending", "work", "streams", "carry")
 
     def __init__(self):
         self.idxs, self.offsets, self.numel = [], {}, 0
         self.flat, self.pending, self.work = None, 0, None
+        self.pflat = None          # the bucket's PERSISTENT storage (a plan that replays a recorded backward writes fixed addresses)
         self.streams = {}          # stream id -> torch.cuda.Stream of every producer of this bucket (this backward)
         self.carry = None          # local sum of the un-synchronised micro-batches (gradient accumulation)
 
@@ -99,7 +100,13 @@ class GradSync:
         self._syncing = bool(self.require_sync)
         dev = plan.params[0].device
         for b in self._cur:
-            if not (self.persistent and b.flat is not None and b.flat.device == dev):
+            if self.persistent:
+                # created once and never replaced: an eager pass in between (profiler, a task left out of the loss) uses fresh
+                # storage below and must not move what the recorded program writes to
+                if b.pflat is None or b.pflat.device != dev:
+                    b.pflat = torch.empty(b.numel, dtype=torch.float32, device=dev)
+                b.flat = b.pflat
+            else:
                 b.flat = torch.empty(b.numel, dtype=torch.float32, device=dev)
             b.pending = len(b.idxs)
             b.work = None

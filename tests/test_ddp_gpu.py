@@ -104,7 +104,9 @@ def _worker(rank, world, port, cfg, q):
         for bi, b in enumerate(sync._plan_layout(plan0)):      # which bucket each parameter travels in (failure diagnostics)
             for j in b.idxs:
                 bucket_of[pidx[id(plan0.params[j])]] = bi
-        for rep in range(5):      # passes 1-2 eager, 3 records the launch program, 4-5 replay it
+        for rep in range(7):      # passes 1-2 eager, 3 records the launch program, 4-5 replay it, 6 eager again (what a
+            for plan in net._plans.values():       # profiler or an absent task does), 7 replays: the recorded addresses must still hold
+                plan.use_programs = rep != 5
             for m in range(nmb):
                 sync.require_sync = (m == nmb - 1)
                 backward(rank, m)
