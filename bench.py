@@ -83,6 +83,46 @@ def pmc_traffic(kernel_label):
     return None
 
 
+def pmc_traffic_live(workload, dtype, kernel_label, timeout_s=150):
+    """HBM bytes per launch of `kernel_label` measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE, then
+    WRITE_SIZE -- separate passes, counters only, as MI355X_MICROARCH.md prescribes), 3 steps each, summarised like
+    scripts/pmc_traffic.py (KiB units, FETCH_SIZE doubled).  None when rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    base = kernel_label.split(":")[-1]
+    name = base.split("<")[0]
+    args = base.split("<")[1].rstrip(">").split(",") if "<" in base else []
+    want = "".join(f"Li{a}E" for a in args)
+    tot = {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]}
+    for counter in tot:
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--workload", workload, "--dtype", dtype, "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-kernel-timing",
+                   "--no-h2d", "--no-pmc"]
+            try:
+                subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, TMPDIR="/tmp"))
+            except subprocess.TimeoutExpired:
+                return None
+            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    k = r["Kernel_Name"]
+                    if r["Counter_Name"] == counter and name in k and ("DF16b" in k or "_Accum" in k or "DF16_" in k) and want in k:
+                        tot[counter][0] += float(r["Counter_Value"])
+                        tot[counter][1] += 1
+    nf, nw = tot["FETCH_SIZE"][1], tot["WRITE_SIZE"][1]
+    if not nf or not nw:
+        return None
+    rd, wr = 2.0 * tot["FETCH_SIZE"][0] * 1024 / nf, tot["WRITE_SIZE"][0] * 1024 / nw
+    return dict(bytes_per_launch=rd + wr, read=rd, write=wr, launches_sampled=nf,
+                source="live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (3 steps each)")
+
+
 def make_mgr(w):
     from types import SimpleNamespace
     return SimpleNamespace(tasks=w["tasks"], train_patch_size=tuple(w["patch"]), train_batch_size=w["batch"],
@@ -223,6 +263,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="take roofline.traffic from the newest profiles/*pmc_hbm_traffic.json "
+                                                          "instead of two live rocprofv3 --pmc child runs")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second timed loop that feeds every step from pinned host memory")
     ap.add_argument("--through-trainer", action="store_true",
                     help="also run the workload through the plug-in surface (BaseTrainer + SyntheticPatchDataset + DataLoader) "
@@ -435,7 +477,15 @@ def main():
                 dom = max(groups, key=lambda k: groups[k]["ms"])
                 g = groups[dom]
                 ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
-                tr = pmc_traffic(dom) if args.dtype == "bf16" else None
+                tr = None
+                if world == 1 and not args.no_pmc:
+                    print("[bench] measuring HBM traffic of the dominant kernel (2 rocprofv3 --pmc child runs) ...", file=sys.stderr, flush=True)
+                    try:
+                        tr = pmc_traffic_live(args.workload, args.dtype, dom)
+                    except Exception as e:      # noqa: BLE001 -- a profiler problem must not cost the bench line
+                        print(f"[bench] live PMC pass failed: {e}", file=sys.stderr, flush=True)
+                if tr is None and args.dtype == "bf16":
+                    tr = pmc_traffic(dom)
                 roofline = dict(bound="mfma", kernel=dom, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
                                 traffic=tr["bytes_per_launch"] if tr else None, traffic_detail=tr,
                                 avg_us_per_launch=g["ms"] * 1e3 / max(g["launches"], 1),
