@@ -1188,8 +1188,8 @@ extern "C" int rx_head_bwd(rx_dtype dt, const float* dout_ncdhw, const rx_act* x
 #define RX_HEADG_MAXK 4
 // ---- InstanceNorm + LeakyReLU of the layer under a task head, with the head's 1x1x1 conv in the same pass -----------
 // rx_head_fwd re-read the activated output (268 MB at cfg2) to form K logits per voxel.  Here the CV lanes that hold one voxel's
-// channel vectors pass the running sums along (lane cv adds its channels to what lane cv-1 computed: the SAME order of fused
-// multiply-adds as head_fwd_kernel's loop over channels, from the rounded output values; logits agree to the last bit or two); the last lane
+// channel vectors pass the running sums along (lane cv adds the partial dot product of its 8 channels to what lane cv-1 holds, from
+// the rounded output values; logits agree with head_fwd_kernel's sequential sum to fp32 round-off); the last lane
 // applies the eval-mode activation and writes the NCDHW fp32 logits.  K <= 4, no residual (decoder.py:115-131).
 template <typename T>
 __global__ __launch_bounds__(256) void in_act_head_fwd_kernel(const T* __restrict__ y, int ldy, long sy, const float* __restrict__ stats,
@@ -1228,22 +1228,29 @@ __global__ __launch_bounds__(256) void in_act_head_fwd_kernel(const T* __restric
       of[j] = Elem<T>::to_f(o.v[j]);
     }
     st16(on + v * ldo + cv * P, o);
-    float acc[RX_HEADG_MAXK];
+    // The CV lanes of a voxel each form the partial dot products of THEIR 8 channels, then hand a running sum along in channel
+    // order (lane cv adds its partial to what lane cv-1 holds).  No divergent region between the cross-lane moves: every lane
+    // computes, a select keeps the owner's value.  (The first version did the adds inside `if (cv == s)`; with a SECOND process
+    // time-slicing the GPU -- two DDP ranks rehearsed on one device -- a few logits per pass then came out different while every
+    // other tensor of the pass stayed bit-identical, with ds_bpermute and with DPP moves alike; 0 of 120 passes with this form,
+    // scripts/fwd_layer_diag.py.  Never observed with one process per GPU.)
+    float part[RX_HEADG_MAXK], acc[RX_HEADG_MAXK];
 #pragma unroll
-    for (int k = 0; k < RX_HEADG_MAXK; ++k) acc[k] = b[k];
-    for (int s = 0; s < CV; ++s) {
-      float prev[RX_HEADG_MAXK];
+    for (int k = 0; k < RX_HEADG_MAXK; ++k) {
+      part[k] = 0.f, acc[k] = b[k];
+      if (k < K) {
 #pragma unroll
-      for (int k = 0; k < RX_HEADG_MAXK; ++k) prev[k] = __shfl_up(acc[k], 1, 64);
-      if (cv == s) {
-#pragma unroll
-        for (int k = 0; k < RX_HEADG_MAXK; ++k) {
-          float t = s == 0 ? b[k] : prev[k];
-#pragma unroll
-          for (int j = 0; j < P; ++j) t += of[j] * w[k][j];
-          acc[k] = t;
-        }
+        for (int j = 0; j < P; ++j) part[k] += of[j] * w[k][j];
       }
+    }
+    for (int s = 0; s < CV; ++s) {
+#pragma unroll
+      for (int k = 0; k < RX_HEADG_MAXK; ++k)
+        if (k < K) {                     // K is uniform: a scalar branch
+          const float prev = __shfl_up(acc[k], 1, 64);
+          const float t = (s == 0 ? b[k] : prev) + part[k];
+          acc[k] = cv == s ? t : acc[k];
+        }
     }
     if (cv == CV - 1) {
       if (act == RX_ACT_SIGMOID) {

@@ -53,11 +53,20 @@ def _worker(rank, world, port, cfg, q):
         losses = {"sheet": BCEDiceLoss(alpha=0.5, beta=0.5), "normals": MaskedCosineLoss()}
         params = [p for p in net.parameters()]
         names = [n for n, _ in net.named_parameters()]
+        fwd_same = []
+
+        logits = {}
 
         def backward(r, m):
             sl = slice(r * B, (r + 1) * B)
             with torch.autocast("cuda", dtype=cfg["dtype"], enabled=cfg["dtype"] is not None):
                 out = net(xs[m][sl])
+                key = (r, m)
+                if key not in logits:
+                    logits[key] = {k: v.detach().clone() for k, v in out.items()}
+                    fwd_same.append(True)
+                else:       # every later forward of the same half batch must reproduce the first one bit for bit
+                    fwd_same.append(all(torch.equal(out[k], logits[key][k]) for k in out))
                 total = 0.0
                 for k in tasks:
                     tgt = seg[m][sl] if k == "sheet" else nrm[m][sl] * seg[m][sl]
@@ -104,7 +113,7 @@ def _worker(rank, world, port, cfg, q):
         for bi, b in enumerate(sync._plan_layout(plan0)):      # which bucket each parameter travels in (failure diagnostics)
             for j in b.idxs:
                 bucket_of[pidx[id(plan0.params[j])]] = bi
-        for rep in range(7):      # passes 1-2 eager, 3 records the launch program, 4-5 replay it, 6 eager again (what a
+        for rep in range(cfg.get("reps", 7)):      # passes 1-2 eager, 3 records the launch program, 4-5 replay it, 6 eager again (what a
             for plan in net._plans.values():       # profiler or an absent task does), 7 replays: the recorded addresses must still hold
                 plan.use_programs = rep != 5
             for m in range(nmb):
@@ -135,7 +144,7 @@ def _worker(rank, world, port, cfg, q):
         # the two ranks' half batches really differ (otherwise the test could not see a skipped collective)
         differs = any(a is not None and not torch.equal(a, b) for a, b in zip(local[(0, 0)], local[(1, 0)]))
         q.put((rank, bool(ok), dict(stats=stats, passes=passes, differs=differs, none_inside=none_inside,
-                                    n_with_grad=n_with_grad, reproducible=reproducible)))
+                                    n_with_grad=n_with_grad, reproducible=reproducible, forward_reproducible=fwd_same)))
         dist.destroy_process_group()
     except Exception as e:      # noqa: BLE001 -- report instead of hanging the parent on q.get
         import traceback
@@ -165,6 +174,9 @@ BASE = dict(patch=(32, 32, 32), batch=1, tasks=["sheet"], dtype=torch.bfloat16, 
     ("se_fp32_two_heads_bias", dict(port_salt=3, dtype=None, tasks=["sheet", "normals"], patch=(16, 16, 16), batch=2,
                                     bucket_bytes=1 << 20, model_config={"squeeze_excitation": True, "conv_bias": True})),
     ("se_accumulate_no_sync", dict(port_salt=4, micro_batches=2, model_config={"squeeze_excitation": True})),
+    # BASELINE configs[3] (cfg4) per-rank workload at FULL size: the cfg2 network, 128^3, batch 2 per rank, bf16, the production
+    # bucket size (853 MB of gradients in 7 buckets) -- two of the eight ranks (eager, eager, recorded, replayed)
+    ("cfg4_rank_workload_full_size", dict(port_salt=5, patch=(128, 128, 128), batch=2, bucket_bytes=128 << 20, reps=4)),
 ])
 def test_two_ranks_real_plan_equal_mean_of_half_batches(name, over):
     cfg = dict(BASE)
@@ -175,6 +187,7 @@ def test_two_ranks_real_plan_equal_mean_of_half_batches(name, over):
         print(f"[{name}] rank {rank}: ok={ok} {json.dumps(info)}", flush=True)
     for rank, ok, info in res:
         assert "error" not in info, info
+        assert all(info["forward_reproducible"]), ("a forward of the same half batch changed", info["forward_reproducible"])
         assert info["reproducible"], "a single-process backward of the same half batch changed: race inside the plan"
         assert info["differs"], "both ranks saw the same data"
         assert info["stats"]["buckets"] >= 2, info
