@@ -12,6 +12,8 @@ asked for raw logits (`NetworkFromConfig.forward_logits`) -- the activation is a
 inference.py:121-133 does it from the target's `activation` key, never twice, so a CPU tensor is an error as everywhere
 else in this package.  Accumulation / blending are a handful of torch slice ops on device tensors: plumbing, not kernels.
 """
+import json
+import os
 from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
@@ -142,3 +144,35 @@ class SlidingWindowInferer:
             f = self.cast_final(name, b)
             out[name + "_final"] = f.cpu().numpy() if f.dtype != torch.int32 else f.cpu().numpy().astype(np.uint16)
         return out
+
+    # ---- output side (inference.py:66-113, 214-263): a zarr v2 group `predictions.zarr` -------------------------------------
+    def write_store(self, volume, output_path: str, compressor: Optional[str] = "zlib") -> str:
+        """run the inference and write `<output_path>/predictions.zarr` with the reference's array set: `<target>_sum` (float32; AFTER
+        the overlap pass it holds the blended prediction, as upstream leaves it), `<target>_count` (float32) and `<target>_final`
+        (uint8 / uint16).  Single-channel targets are stored (Z, Y, X), others (c, Z, Y, X); chunks = the patch size (inference.py:
+        76-90).  Refuses to overwrite an existing store (inference.py:67-72).  The reference compresses with Blosc/zstd (numcodecs,
+        absent here): chunks are written with zlib or raw through `dataloading.zarr_lite` -- any zarr v2 reader opens them."""
+        from .dataloading import zarr_lite
+        store = os.path.join(output_path, "predictions.zarr")
+        if os.path.isdir(store):
+            raise FileExistsError(f"Zarr store '{store}' already exists. Aborting to prevent overwrite.")
+        sums, count = self.accumulate(volume)
+        os.makedirs(store)
+        with open(os.path.join(store, ".zgroup"), "w") as f:
+            json.dump({"zarr_format": 2}, f)
+        pz, py, px = self.patch
+        cnt = count.cpu().numpy()
+        for name, s_t in sums.items():
+            blended = self.blend(name, s_t, count)
+            final = self.cast_final(name, blended)
+            final_np = final.cpu().numpy() if final.dtype != torch.int32 else final.cpu().numpy().astype(np.uint16)
+            b_np = blended.cpu().numpy()
+            c = b_np.shape[0]
+            if c == 1:
+                b_np, final_np, chunks = b_np[0], final_np[0], (pz, py, px)
+            else:
+                chunks = (c, pz, py, px)
+            zarr_lite.write_array(os.path.join(store, f"{name}_sum"), b_np, chunks, compressor=compressor)
+            zarr_lite.write_array(os.path.join(store, f"{name}_count"), cnt, (pz, py, px), compressor=compressor)
+            zarr_lite.write_array(os.path.join(store, f"{name}_final"), final_np, chunks, compressor=compressor)
+        return store

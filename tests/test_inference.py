@@ -134,3 +134,37 @@ def test_inference_with_stochastic_depth_is_deterministic_and_eval_mode():
     with torch.no_grad():
         act = net(x)["sheet"]
     assert torch.allclose(torch.sigmoid(l1), act, atol=1e-6)
+
+
+def test_output_store_layout_matches_the_reference_rules(tmp_path, monkeypatch):
+    """the output side (reference inference.py:66-113, 214-263) on the CPU: `write_store` needs device accumulators, so the patch
+    loop is replaced by synthetic sums / counts; what is checked is the store itself -- array names, shapes (single channel squeezed),
+    chunking by patch size, dtypes, values readable through an independent reader path, the refusal to overwrite."""
+    import json
+    inf = _product()
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.dataloading import zarr_lite
+    rng = np.random.default_rng(1)
+    Z, Y, X = 20, 24, 40
+    cnt = rng.integers(0, 3, size=(Z, Y, X)).astype(np.float32)
+    sums = {"sheet": torch.from_numpy(rng.random((1, Z, Y, X)).astype(np.float32) * cnt),
+            "normals": torch.from_numpy(rng.normal(size=(3, Z, Y, X)).astype(np.float32) * cnt)}
+    targets = {"sheet": {"channels": 1, "activation": "sigmoid"}, "normals": {"channels": 3, "activation": "none"}}
+    runner = inf.SlidingWindowInferer(model=None, targets=targets, patch_size=(16, 16, 16), device="cpu")
+    monkeypatch.setattr(runner, "accumulate", lambda volume: (sums, torch.from_numpy(cnt)))
+    store = runner.write_store(None, str(tmp_path / "out"))
+    assert store.endswith("predictions.zarr") and json.load(open(os.path.join(store, ".zgroup"))) == {"zarr_format": 2}
+    assert sorted(os.listdir(store)) == sorted([".zgroup", "sheet_sum", "sheet_count", "sheet_final", "normals_sum", "normals_count",
+                                                "normals_final"])
+    sheet = zarr_lite.open(os.path.join(store, "sheet_final"))
+    assert sheet.shape == (Z, Y, X) and sheet.dtype == np.uint8 and tuple(sheet.chunks) == (16, 16, 16)
+    nrm = zarr_lite.open(os.path.join(store, "normals_final"))
+    assert nrm.shape == (3, Z, Y, X) and nrm.dtype == np.uint16 and tuple(nrm.chunks) == (3, 16, 16, 16)
+    blended = zarr_lite.open(os.path.join(store, "sheet_sum"))[:, :, :]
+    want = sums["sheet"][0].numpy().copy()
+    want[cnt > 0] /= cnt[cnt > 0]
+    assert np.allclose(blended, want, rtol=1e-6, atol=1e-7)
+    assert np.array_equal(sheet[:, :, :], np.clip(want * 255.0, 0, 255).astype(np.uint8))
+    assert np.array_equal(zarr_lite.open(os.path.join(store, "normals_count"))[:, :, :], cnt)
+    with pytest.raises(FileExistsError):
+        runner.write_store(None, str(tmp_path / "out"))
