@@ -2154,14 +2154,24 @@ __global__ __launch_bounds__(256) void sqnorm_multi_kernel(const SqnormMulti t, 
   if (threadIdx.x == 0) partial[b] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void sqnorm_finalize_kernel(const float* __restrict__ partial, int nblocks, float max_norm,
-                                                              float* __restrict__ out /* [2]: norm, clip coefficient */) {
-  __shared__ double red[256];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partial[i];
-  red[threadIdx.x] = s;
+// (one workgroup of 1024 threads, eight loads in flight per thread: the 52 K partials of cfg2 took 64 us as a 256-thread serial
+// load chain at the serial end of the step; the summation order stays fixed)
+__global__ __launch_bounds__(1024) void sqnorm_finalize_kernel(const float* __restrict__ partial, int nblocks, float max_norm,
+                                                               float* __restrict__ out /* [2]: norm, clip coefficient */) {
+  __shared__ double red[1024];
+  double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int i = threadIdx.x;
+  for (; i + 7 * 1024 < nblocks; i += 8 * 1024) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[i + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += (double)v[u];
+  }
+  for (; i < nblocks; i += 1024) s[0] += (double)partial[i];
+  red[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = 512; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
@@ -2205,7 +2215,7 @@ extern "C" int rx_grad_norm_clip(int count, const float* const* grad, const long
     done += blocks;
     i0 += k;
   }
-  hipLaunchKernelGGL(sqnorm_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, (int)done, max_norm, out);
+  hipLaunchKernelGGL(sqnorm_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)partial, (int)done, max_norm, out);
   RX_CHECK_LAUNCH("rx_grad_norm_clip");
   return RX_OK;
 }
