@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(const float* __restri
 // ---------------------------------------------------------------------------------------------
 __device__ inline int lane_voxel_ig(int l) { return l < 4 ? l : l < 12 ? l + 12 : l < 16 ? l - 8 : l < 20 ? l + 8 : l < 28 ? l - 12 : l; }
 
-template <typename T>
+template <typename T, int ABL = 0>      // ABL: timing ablations (-DRX_ABLATION=1 builds only): 1 no global loads, 2 no MFMAs, 4 no LDS traffic
 __global__ __launch_bounds__(256, 2) void igemm_fat_kernel(const T* __restrict__ in, const T* __restrict__ w, float* __restrict__ slab,
                                                            const IgemmGeom g, int NV /* N * Vq */, int nsteps_total) {
   constexpr int P = Elem<T>::PER16;
@@ -278,25 +278,47 @@ __global__ __launch_bounds__(256, 2) void igemm_fat_kernel(const T* __restrict__
   const int st_begin = (int)((long)nsteps_total * split / g.ksplit);
   const int st_end = (int)((long)nsteps_total * (split + 1) / g.ksplit);
 
+  // SQ counters of this kernel: 39 % of the wave cycles issuing (VALU 21 %, two waves per SIMD), MFMA busy 14 % -- it was bound by
+  // the instruction stream of the gather, ~20 VALU + a branch per activation row and K step against 16 MFMAs per wave.  The row
+  // offsets only change with the TAP, not with the channel chunk: they are recomputed when the tap changes (every Ci/128 steps) and
+  // kept as one 32-bit element offset per row (-1 = zero padding).
   u32x4 xr[XP], wr[WP];
+  int xo[XP], wo = 0, cur_tap = -1;
   auto load_step = [&](int st) {
     const int tap = st / nkc, cc = st - tap * nkc;
-    const RxTap tp = g.taps[P_.tap0 + tap];
+    if (tap != cur_tap) {                     // uniform
+      cur_tap = tap;
+      const RxTap tp = g.taps[P_.tap0 + tap];
+#pragma unroll
+      for (int p = 0; p < XP; ++p) {
+        const int z = gz[p] + tp.dz, y = gy[p] + tp.dy, x = gx[p] + tp.dx;
+        const bool ok = rok[p] & ((unsigned)z < (unsigned)g.Zi) & ((unsigned)y < (unsigned)g.Yi) & ((unsigned)x < (unsigned)g.Xi);
+        xo[p] = ok ? (int)(gbase[p] + ((long)(z * g.Yi + y) * g.Xi + x) * g.ldi) : -1;
+      }
+      wo = (int)(((long)tp.w * g.Co + n0 + rbase) * g.Ci + chunk * P);
+    }
+    const int ko = cc * KE;
+    if (ABL & 1) {
+#pragma unroll
+      for (int p = 0; p < XP; ++p) xr[p] = u32x4{(unsigned)(xo[p] + ko), 1u, 2u, 3u};
+#pragma unroll
+      for (int p = 0; p < WP; ++p) wr[p] = u32x4{(unsigned)(wo + ko), 1u, 2u, 3u};
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
-      const int z = gz[p] + tp.dz, y = gy[p] + tp.dy, x = gx[p] + tp.dx;
-      const bool ok = rok[p] && (unsigned)z < (unsigned)g.Zi && (unsigned)y < (unsigned)g.Yi && (unsigned)x < (unsigned)g.Xi;
-      u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (ok) v = *reinterpret_cast<const u32x4*>(in + gbase[p] + ((long)(z * g.Yi + y) * g.Xi + x) * g.ldi + cc * KE);
-      xr[p] = v;
+      const int o = xo[p] < 0 ? 0 : xo[p] + ko;           // always a valid address: the load is unconditional, the select zeroes padding
+      const u32x4 v = *reinterpret_cast<const u32x4*>(in + o);
+      xr[p] = xo[p] < 0 ? u32x4{0u, 0u, 0u, 0u} : v;
     }
 #pragma unroll
-    for (int p = 0; p < WP; ++p) {
-      const int row = rbase + 16 * p;
-      wr[p] = *reinterpret_cast<const u32x4*>(w + ((long)tp.w * g.Co + n0 + row) * g.Ci + cc * KE + chunk * P);
-    }
+    for (int p = 0; p < WP; ++p) wr[p] = *reinterpret_cast<const u32x4*>(w + wo + (long)(16 * p) * g.Ci + ko);
   };
   auto store_step = [&]() {
+    if (ABL & 4) {          // keep the values alive without touching LDS
+      if (xr[0][0] == 0x7fffffffu && wr[0][0] == 0x7ffffffeu) sX[0] = xr[1];
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
       const int row = rbase + 16 * p;
@@ -331,10 +353,20 @@ __global__ __launch_bounds__(256, 2) void igemm_fat_kernel(const T* __restrict__
 #pragma unroll
     for (int ks = 0; ks < KC / 2; ++ks) {
       const int c = ks * 2 + fh;
-      const u32x4 b = xrow[c ^ xm];
-      const u32x4 a0 = wrow0[c ^ wm], a1 = wrow1[c ^ wm];
-      Mma<T>::run(acc[0], a0, b);
-      Mma<T>::run(acc[1], a1, b);
+      u32x4 b, a0, a1;
+      if (ABL & 4) {
+        b = u32x4{(unsigned)c, (unsigned)st, 2u, 3u}, a0 = b, a1 = b;
+      } else {
+        b = xrow[c ^ xm];
+        a0 = wrow0[c ^ wm], a1 = wrow1[c ^ wm];
+      }
+      if (ABL & 2) {
+        acc[0][ks] += __builtin_bit_cast(float, a0[0] ^ b[1]);
+        acc[1][ks] += __builtin_bit_cast(float, a1[2] ^ b[3]);
+      } else {
+        Mma<T>::run(acc[0], a0, b);
+        Mma<T>::run(acc[1], a1, b);
+      }
     }
   }
 
@@ -430,7 +462,25 @@ static int igemm_launch(rx_dtype dt, const void* in, const void* w, const float*
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fat_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
           }
+#if RX_ABLATION
+          {
+            const char* ea = getenv("RX_FAT_ABL");
+            const int abl = ea ? atoi(ea) : 0;
+#define RX_FAT_L(A)                                                                                                                     \
+  case A:                                                                                                                               \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fat_kernel<bf16_t, A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((igemm_fat_kernel<bf16_t, A>), grid, dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)w, (float*)ws, g, (int)NV, nsteps); \
+    break;
+            switch (abl) {
+              RX_FAT_L(1) RX_FAT_L(2) RX_FAT_L(3) RX_FAT_L(4) RX_FAT_L(5) RX_FAT_L(6) RX_FAT_L(7)
+              default:
+                hipLaunchKernelGGL((igemm_fat_kernel<bf16_t>), grid, dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)w, (float*)ws, g, (int)NV, nsteps);
+            }
+#undef RX_FAT_L
+          }
+#else
           hipLaunchKernelGGL((igemm_fat_kernel<bf16_t>), grid, dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)w, (float*)ws, g, (int)NV, nsteps);
+#endif
         } else {
           static bool attr = false;
           if (!attr) {
