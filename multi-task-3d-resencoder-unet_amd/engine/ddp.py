@@ -40,10 +40,11 @@ class _Bucket:
 
 
 class GradSync:
-    def __init__(self, process_group=None, bucket_bytes: int = 128 << 20, average: bool = True):
+    def __init__(self, process_group=None, bucket_bytes: int = 128 << 20, average: bool = True, force_collectives: bool = False):
         self.group = process_group
         self.bucket_bytes = int(bucket_bytes)
         self.average = average
+        self.force_collectives = force_collectives      # issue the collectives even in a world of one (backend rehearsal on one GPU)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # RCCL averages inside the collective (ncclAvg; probed on this image with scripts/nccl_avg_probe.py): no
         # pre-scale pass over the 853 MB of gradients.  gloo has no AVG -> pre-scale by 1/world there.
@@ -142,7 +143,7 @@ class GradSync:
             # stays local; the stepping micro-batch picks it up (a copy when the bucket storage is reused by the next backward)
             b.carry = b.flat.clone() if self.persistent else b.flat
             return
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return
         self.stats["collectives"] += 1
         if self.average and self._native_avg and b.flat.is_cuda:
@@ -153,7 +154,7 @@ class GradSync:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _launch(self, b):
-        if self.world == 1 and b.carry is None and self._syncing:
+        if self.world == 1 and b.carry is None and self._syncing and not self.force_collectives:
             return
         if b.flat.is_cuda:
             # every stream that produced into this bucket: the kernels enqueued there so far include all of the bucket's

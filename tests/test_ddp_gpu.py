@@ -257,3 +257,74 @@ def test_trainer_two_ranks_accumulation_keeps_replicas_identical(tmp_path):
     losses = res[0][2]
     assert len(losses) == 2 and losses[1] < losses[0], losses
     assert res[0][3] > 0
+
+
+def _rccl_worker(port, q):
+    try:
+        for p in (ROOT, os.path.join(ROOT, "oracle")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        import mt3d_amd  # noqa: F401
+        import resenc_oracle as oracle
+        from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
+        from mt3d_amd.engine.ddp import GradSync, broadcast_parameters
+        from mt3d_amd.training.losses.losses import BCEDiceLoss
+        from mt3d_amd.training.optim import EngineAdamW, clip_and_step
+        tasks = {"sheet": TASKS["sheet"]}
+        mgr = oracle.make_mgr((32, 32, 32), tasks, 1, 2, True, {"squeeze_excitation": True})
+
+        def run(with_sync):
+            torch.manual_seed(3)
+            net = NetworkFromConfig(mgr).cuda().train()
+            if with_sync:
+                broadcast_parameters(net)
+            params = list(net.parameters())
+            opt = EngineAdamW(params, model=None, lr=1e-3, weight_decay=0.0)
+            sync = GradSync(bucket_bytes=8 << 20, force_collectives=True) if with_sync else None
+            gen = torch.Generator().manual_seed(5)
+            x = torch.rand((2, 1, 32, 32, 32), generator=gen).cuda()
+            t = (torch.rand((2, 1, 32, 32, 32), generator=gen) > 0.8).float().cuda()
+            loss_fn = BCEDiceLoss(alpha=0.5, beta=0.5)
+            losses = []
+            for _ in range(6):              # eager, eager, recorded, replayed ...
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    out = net(x)
+                    if sync is not None:
+                        for plan in net._plans.values():
+                            plan.grad_sync = sync
+                    loss = loss_fn(out["sheet"], t)
+                loss.backward()
+                clip_and_step(opt, params, 3)
+                opt.zero_grad(set_to_none=True)
+                losses.append(loss.item())
+            return losses, [p.detach().clone() for p in params], (dict(sync.stats) if sync else None)
+
+        l0, p0, _ = run(False)
+        l1, p1, stats = run(True)
+        same = l0 == l1 and all(torch.equal(a, b) for a, b in zip(p0, p1))
+        q.put((bool(same), dict(stats=stats, backend=dist.get_backend(), losses=(l0[-1], l1[-1]))))
+        dist.destroy_process_group()
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        q.put((False, dict(error=f"{type(e).__name__}: {e}", tb=traceback.format_exc()[-2000:])))
+
+
+def test_rccl_backend_rehearsal_in_a_world_of_one():
+    """the production backend ("nccl" == RCCL) as far as ONE GPU can exercise it: a world of one rank with the collectives forced
+    (`GradSync(force_collectives=True)`): `all_reduce(op=AVG, async_op=True)` on the collective stream, `work.wait()`, persistent
+    buckets under recorded launch programs, `broadcast_parameters`, the engine's AdamW reading the bucket views.  An average over one
+    rank is the identity, so six training steps must leave losses and parameters bit-identical to the run without a synchroniser.
+    (Two or more RCCL ranks need one GPU each: unmeasured on hardware)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(35500 + (os.getpid() % 2000), q))
+    p.start()
+    ok, info = q.get(timeout=420)
+    p.join(timeout=60)
+    assert "error" not in info, info
+    assert info["backend"] == "nccl" and info["stats"]["buckets"] >= 2 and info["stats"]["collectives"] == info["stats"]["buckets"], info
+    assert ok, info
