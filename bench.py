@@ -49,6 +49,17 @@ WORKLOADS = {
     "cfg2se": dict(patch=(128, 128, 128), in_channels=1, batch=2, autoconfigure=True, model_config={"squeeze_excitation": True},
                    tasks={"sheet": {"channels": 1, "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss",
                                     "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}),
+    # the reference's own task files at their own sizes (values read from tasks/ink.yaml / tasks/dumb.yaml: autoconfigure, conv_bias,
+    # squeeze_excitation, batch 3): ink = anisotropic 14 x 256 x 256, 7 stages; dumb = 128^3 with sheet + normals decoders
+    "inkyaml": dict(patch=(14, 256, 256), in_channels=1, batch=3, autoconfigure=True,
+                    model_config={"conv_bias": True, "squeeze_excitation": True},
+                    tasks={"ink": {"channels": 1, "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss",
+                                   "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}),
+    "dumbyaml": dict(patch=(128, 128, 128), in_channels=1, batch=3, autoconfigure=True,
+                     model_config={"conv_bias": True, "squeeze_excitation": True},
+                     tasks={"sheet": {"channels": 1, "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss",
+                                      "loss_kwargs": {"alpha": 0.5, "beta": 0.5}},
+                            "normals": {"channels": 3, "activation": "none", "weight": 1, "loss_fn": "MaskedCosineLoss"}}),
     # configs[0]: 64^3 plumbing case
     "cfg1": dict(patch=(64, 64, 64), in_channels=1, batch=2, autoconfigure=True, model_config={},
                  tasks={"sheet": {"channels": 1, "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss",

@@ -124,6 +124,16 @@ FULL = {
                      "features_per_stage": [32, 64, 128, 256, 320, 320], "num_stages": 6, "n_blocks_per_stage": [1, 3, 4, 6, 6, 6],
                      "kernel_sizes": [3] * 6, "n_conv_per_stage_decoder": [1] * 5, "strides": [1, 2, 2, 2, 2, 2]},
                  tasks={"sheet": {"channels": 1, "activation": "none", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}),
+    # the reference's own task files at their own sizes (values read from tasks/ink.yaml and tasks/dumb.yaml: autoconfigure true, conv_bias
+    # true, squeeze_excitation true, batch 3).  ink: anisotropic patch 14 x 256 x 256 -> 7 stages with (1,2,2) strides; dumb: 128^3 with a
+    # sheet head and a 3-channel normals head.  (SqueezeExcite: parity unpinned; these are engine-consistency properties.)
+    "ink_yaml": dict(patch=(14, 256, 256), cin=1, autoconf=True, dtype=torch.bfloat16, lin_tol=1.2e-1, batch=3,
+                     mc={"conv_bias": True, "squeeze_excitation": True},
+                     tasks={"ink": {"channels": 1, "activation": "none", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}),
+    "dumb_yaml": dict(patch=(128, 128, 128), cin=1, autoconf=True, dtype=torch.bfloat16, lin_tol=1.5e-1, batch=3,
+                      mc={"conv_bias": True, "squeeze_excitation": True},
+                      tasks={"sheet": {"channels": 1, "activation": "none", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}},
+                             "normals": {"channels": 3, "activation": "none", "loss_fn": "MaskedCosineLoss"}}),
 }
 
 
@@ -136,13 +146,14 @@ def test_full_size_multi_head_and_320cap_configs(name):
     from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
     from mt3d_amd.training.losses.losses import LOSS_FN_MAP
     c = FULL[name]
-    mgr = oracle.make_mgr(c["patch"], c["tasks"], c["cin"], 1, c["autoconf"], c["mc"])
+    B = c.get("batch", 1)
+    mgr = oracle.make_mgr(c["patch"], c["tasks"], c["cin"], B, c["autoconf"], c["mc"])
     torch.manual_seed(0)
     net = NetworkFromConfig(mgr).cuda()
     net.compute_dtype = c["dtype"]
     gen = torch.Generator(device="cuda").manual_seed(7)
-    x = torch.rand((1, c["cin"], *c["patch"]), device="cuda", generator=gen)
-    shapes = {k: (1, v["channels"], *c["patch"]) for k, v in c["tasks"].items()}
+    x = torch.rand((B, c["cin"], *c["patch"]), device="cuda", generator=gen)
+    shapes = {k: (B, v["channels"], *c["patch"]) for k, v in c["tasks"].items()}
 
     def run(gs):
         net.zero_grad(set_to_none=True)
@@ -171,14 +182,28 @@ def test_full_size_multi_head_and_320cap_configs(name):
         ref = a[n].double() + b[n].double()
         if ref.norm() < 1e-9:
             continue
-        err = ((s12[n].double() - ref).norm() / ref.norm()).item()
-        assert err < c["lin_tol"], (n, err)
+        if n.endswith(".conv.bias"):
+            # a conv bias under InstanceNorm (conv_bias: true, as in the reference's ink/dumb task files): the norm removes the mean,
+            # so its gradient is analytically ZERO and what arrives is round-off -- linearity of noise is not a property.  Measured
+            # (scripts/bias_noise_diag.py): fp32 compute 1e-8..1e-6 of the norm of the weight gradient of the same conv, bf16 1e-4 in the
+            # deep stages and up to 7e-2 at full resolution (sum of 2.7M..6.3M bf16-rounded values per channel); sanity bound only.
+            wn = a[n[:-len("bias")] + "weight"].double().norm()
+            assert a[n].double().norm() <= 0.2 * wn, (n, a[n].double().norm().item(), wn.item())
+            continue
+        err = (s12[n].double() - ref).norm().item()
+        floor = 0.0
+        if n.endswith(".bias") and ".transpconvs." in n:
+            # a constant added to the upsampled half of a concat goes through a conv and an InstanceNorm: only the zero-padded border
+            # keeps it from cancelling, so this gradient is a small residue of large terms; allow round-off of the size seen on the
+            # module's weight gradient
+            floor = 1e-2 * a[n[:-len("bias")] + "weight"].double().norm().item()
+        assert err < c["lin_tol"] * ref.norm().item() + floor, (n, err / ref.norm().item(), floor)
     # a short optimisation on one synthetic batch reduces the loss
-    seg = (torch.rand((1, 1, *c["patch"]), device="cuda", generator=gen) > 0.8).float()
+    seg = (torch.rand((B, 1, *c["patch"]), device="cuda", generator=gen) > 0.8).float()
     targets = {}
     for k, info in c["tasks"].items():
         if info["loss_fn"] == "MaskedCosineLoss":
-            v = torch.randn((1, info["channels"], *c["patch"]), device="cuda", generator=gen)
+            v = torch.randn((B, info["channels"], *c["patch"]), device="cuda", generator=gen)
             targets[k] = torch.nn.functional.normalize(v, dim=1) * seg
         else:
             targets[k] = seg
