@@ -149,7 +149,13 @@ extern "C" int rx_event_new(void) {
 static hipEvent_t* event_slot(int slot) {
   if (slot < 0 || slot >= g_event_next) return nullptr;
   if (!g_event_made[slot]) {
-    if (hipEventCreateWithFlags(&g_events[slot], hipEventDisableTiming) != hipSuccess) return nullptr;
+    // These events only order streams of ONE device (producer kernel -> consumer kernel; every kernel still ends with its own
+    // device-scope release), nobody synchronises the HOST on them: created without the system-scope fence (no cache write-back /
+    // invalidate towards the host when the event fires; cfg2 step 18.01 -> 17.84 ms).  RX_EVENT_FLAGS (A/B knob): 0 plain, 1 without
+    // the system-scope fence (default), 2 device-scope release.
+    static const int mode = [] { const char* v = getenv("RX_EVENT_FLAGS"); return v ? atoi(v) : 1; }();
+    unsigned flags = hipEventDisableTiming | (mode == 1 ? hipEventDisableSystemFence : mode == 2 ? hipEventReleaseToDevice : 0u);
+    if (hipEventCreateWithFlags(&g_events[slot], flags) != hipSuccess) return nullptr;
     g_event_made[slot] = true;
   }
   return &g_events[slot];

@@ -129,7 +129,7 @@ class Plan:
         # weight gradients on a side HIP stream (off the dependency chain); RX_OVERLAP_WGRAD=0 keeps one stream
         self.overlap_wgrad = os.environ.get("RX_OVERLAP_WGRAD", "1") != "0"
         # dy slots per shape (RX_DY_RING): with 2 the main stream stalls whenever the side stream is more than one layer behind
-        self.dy_ring = max(2, int(os.environ.get("RX_DY_RING", "2")))
+        self.dy_ring = max(2, int(os.environ.get("RX_DY_RING", "4")))
         self._side = None
         self._ws2 = None
         self._dy_turn: Dict[tuple, int] = {}
