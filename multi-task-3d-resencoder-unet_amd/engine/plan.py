@@ -248,6 +248,7 @@ class Plan:
             if s not in (1, 2):
                 raise UnsupportedConfig(f"stride {s} has no HIP kernel (1 or 2 per axis)")
         cin, cout = conv.in_channels, conv.out_channels
+        first_of_net = first_of_net or x is None      # x is None: the layer reads the NCDHW image (the stem; without one, the first block)
         in_dims = x.act.dims[1:] if not first_of_net else self.spatial
         odims = self._out_dims(in_dims, kernel, stride)
         y = self._new(odims, cout, f"y:{len(tape)}")
@@ -321,8 +322,14 @@ class Plan:
     def _emit_block(self, tape, blk, x: AT, out: Optional[AT] = None):
         """BasicBlockD / BottleneckD: skip path, main path, fused `nonlin(IN(conv_k(..)) + skip)`."""
         r = x
+        if x is None and not any(hasattr(op, "spec") for op in blk.skip_ops):
+            raise UnsupportedConfig("do_stem=False: the first block adds the raw image to its output (identity / pooled skip); "
+                                    "the HIP path needs a projection on the skip path")
         for op in blk.skip_ops:
             if isinstance(op, (nn.AvgPool3d, nn.AvgPool2d)):
+                if r is None:
+                    raise UnsupportedConfig("do_stem=False with a strided first block: the image would be pooled on the skip path "
+                                            "(the first-layer kernel reads the NCDHW image at stride 1)")
                 st = self._k3(op.stride if isinstance(op.stride, (list, tuple)) else [op.stride] * (2 if self.two_d else 3))
                 odims = tuple(d // s for d, s in zip(r.act.dims[1:], st))
                 p = self._new(odims, r.act.c, f"pool:{len(tape)}")
@@ -343,9 +350,6 @@ class Plan:
     def _build(self):
         net = self.net
         enc = net.shared_encoder
-        if enc.stem is None:
-            raise UnsupportedConfig("do_stem=False: the HIP path needs the stem (it converts the NCDHW image to the "
-                                    "engine's channels-last layout)")
         tasks = list(net.task_decoders.keys())
         n_st = len(enc.stages)
         feats = list(enc.output_channels)
@@ -380,9 +384,10 @@ class Plan:
         # ---- encoder
         tape = self.enc_tape
         x = None
-        stem_mods = list(enc.stem.convs)
-        h = self._emit_cdnr(tape, stem_mods[0], None, first_of_net=True)
-        for m in stem_mods[1:]:
+        # do_stem=False (encoder.py:81-89): the first block of stage 0 reads the NCDHW image itself -- its first main-path conv and
+        # its skip projection both run on the first-layer kernels (h stays None until then)
+        h = None
+        for m in (list(enc.stem.convs) if enc.stem is not None else []):
             h = self._emit_cdnr(tape, m, h)
         skips: List[AT] = []
         for s in range(n_st):

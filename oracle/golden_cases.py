@@ -86,6 +86,16 @@ CASES = {
                           seed=11, data_seed=1, train=True,
                           full_grads=("stages.0.blocks.0.conv1.conv.weight", "sheet.transpconvs.1.weight",
                                       "sheet.stages.1.convs.0.conv.weight")),
+    # do_stem: false (encoder.py:81-89): the first residual block reads the image itself (conv1 1->32 and the 1x1x1 projection of
+    # its skip path are both first-layer convolutions), 2 input channels
+    "no_stem": dict(patch=(16, 16, 16), batch=2, in_channels=2, tasks=TASKS_SIGMOID_SHEET, autoconfigure=False,
+                    model_config=_manual(do_stem=False), seed=11, data_seed=1, train=True,
+                    full_grads=("stages.0.blocks.0.conv1.conv.weight", "stages.0.blocks.0.skip.0.conv.weight",
+                                "sheet.transpconvs.1.weight")),
+    # the same on the plain-conv encoder: stage 0's first ConvDropoutNormReLU is the first layer
+    "no_stem_plain": dict(patch=(16, 16, 16), batch=2, in_channels=1, tasks=TASKS_SIGMOID_SHEET, autoconfigure=False,
+                          model_config=_manual(do_stem=False, basic_encoder_block="ResidualBlock"), seed=11, data_seed=1, train=True,
+                          full_grads=("shared_encoder.stages.0.0.convs.0.conv.weight", "sheet.transpconvs.1.weight")),
 }
 
 # Cases WITHOUT a reference fixture -- PARITY UNPINNED: SqueezeExcite / DropPath live in the un-vendored
