@@ -118,6 +118,12 @@ int rx_convT3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* dy, float*
 size_t rx_instnorm_stats_workspace(const rx_act* y);
 int rx_instnorm_stats(rx_dtype dt, const rx_act* y, float eps, float* stats, void* ws, size_t ws_bytes,
                       void* stream);
+/* nn.Dropout3d / nn.Dropout2d (channel dropout, training mode) between a conv and its InstanceNorm
+ * (simple_conv_blocks.py:57-66; build_network_from_config.py:169-170 `dropout_op_kwargs`): IN(s*y) with s = 1/(1-p) equals
+ * (y - mean)/sqrt(var + eps*(1-p)^2) for a kept (n, c) plane and 0 for a dropped one -- so the caller computes the statistics
+ * with eps*(1-p)^2 and this call sets rstd = 0 for the dropped planes (stats[i].rstd *= keep[i], keep[n*C+c] in {0,1}); every
+ * forward and backward InstanceNorm entry point then does the right thing from `stats` alone, no pass over y. */
+int rx_instnorm_stats_mask(float* stats, const float* keep, int count, void* stream);
 /* out = lrelu_slope( (y-mean)*rstd + residual ); residual may be NULL; slope = 1 -> no activation */
 int rx_instnorm_act_fwd(rx_dtype dt, const rx_act* y, const float* stats, const rx_act* residual,
                         const rx_act* out, float slope, void* stream);

@@ -237,6 +237,26 @@ extern "C" int rx_instnorm_stats(rx_dtype dt, const rx_act* y, float eps, float*
   return RX_OK;
 }
 
+// ---- nn.Dropout3d / nn.Dropout2d in front of an InstanceNorm (simple_conv_blocks.py:57-66: conv -> dropout -> norm) --------
+// Channel dropout multiplies a whole (n, c) plane by 0 or by s = 1/(1-p).  InstanceNorm(affine=False) of s*y is
+// (y - mean) / sqrt(var + eps/s^2): the kept planes need no pass over y at all, only the smaller eps (the caller passes
+// eps*(1-p)^2 to the statistics); a dropped plane normalises to exactly 0, which is rstd = 0 in the (mean, rstd) pair every
+// forward AND backward InstanceNorm kernel of this library works from (xhat = 0, dy = rstd * (...) = 0).  This entry point
+// applies the second half: stats[i].rstd *= keep[i], keep[n*C + c] in {0, 1}.
+__global__ __launch_bounds__(256) void stats_mask_kernel(float* __restrict__ stats, const float* __restrict__ keep, int count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < count) stats[2 * i + 1] *= keep[i];
+}
+
+extern "C" int rx_instnorm_stats_mask(float* stats, const float* keep, int count, void* stream) {
+  RX_RECORD(stream, [=](void* s) { return rx_instnorm_stats_mask(stats, keep, count, s); });
+  if (!stats || !keep || count < 0) RX_FAIL(RX_EINVAL, "rx_instnorm_stats_mask: bad arguments");
+  if (count == 0) return RX_OK;
+  hipLaunchKernelGGL(stats_mask_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, keep, count);
+  RX_CHECK_LAUNCH("rx_instnorm_stats_mask");
+  return RX_OK;
+}
+
 // (mean, rstd) from per-chunk partial sums laid out like colreduce_kernel's (rx_conv_halo.hip leaves such partials behind
 // when a persistent conv kernel accumulates the statistics of its own output)
 void rx_stats_finalize_launch(const float* partial, int N, int nchunks, int C, double V, float eps, float* stats, hipStream_t st) {

@@ -417,6 +417,11 @@ def instnorm_stats(y, stats, eps=1e-5, ws=None):
           "rx_instnorm_stats")
 
 
+def instnorm_stats_mask(stats, keep):
+    """channel dropout in front of an InstanceNorm: rstd = 0 for the dropped (n, c) planes (see rx_instnorm_stats_mask)"""
+    check(load().rx_instnorm_stats_mask(_ptr(stats), _ptr(keep), int(keep.numel()), stream_ptr()), "rx_instnorm_stats_mask")
+
+
 def instnorm_act_fwd(y, stats, out, slope=0.01, residual=None):
     check(load().rx_instnorm_act_fwd(_code(y.dtype), byref(y.desc()), _ptr(stats),
                                      byref(residual.desc()) if residual is not None else None, byref(out.desc()),

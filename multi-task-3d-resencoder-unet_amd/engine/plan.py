@@ -142,6 +142,7 @@ class Plan:
         self._ev_join = None                      # side -> main
         self._pack_groups = None                  # [(entries, event slot)] in first-use order (static per plan)
         self._gates: List[dict] = []              # SqueezeExcite / DropPath state of every gated block, forward order
+        self._drops: List[dict] = []              # channel-dropout layers (dropout_op_kwargs p > 0), forward order
         # Launch programs (default on; RX_PROGRAMS=0 = one ctypes call per launch): the forward / backward lists are static, so
         # after two eager passes each is RECORDED once by the library while it executes (rx_prog_begin/end) and every later
         # step replays it with one C call -- the same launches on the same two streams, without ~700 host-language calls
@@ -233,8 +234,13 @@ class Plan:
         `residual`/`final_slope` fuse the block epilogue `nonlin(out + residual)` into the same
         elementwise pass.  Returns the activated output."""
         sp = m.spec()
-        if sp["dropout_p"] != 0.0:
-            raise UnsupportedConfig("dropout p > 0 has no HIP kernel (all reference configs use p = 0)")
+        p_drop = float(sp["dropout_p"])
+        if p_drop != 0.0:
+            if not isinstance(m.dropout, (nn.Dropout3d, nn.Dropout2d)) or not (0.0 < p_drop < 1.0):
+                raise UnsupportedConfig("only channel dropout (nn.Dropout3d / nn.Dropout2d, build_network_from_config.py:196-205) "
+                                        "with 0 < p < 1 runs on the HIP path")
+            if residual is not None or se is not None or drop_p > 0.0:
+                raise UnsupportedConfig("dropout inside a block epilogue is never produced by NetworkFromConfig")
         if sp["nonlin_first"]:
             raise UnsupportedConfig("nonlin_first=True is never selected by NetworkFromConfig")
         eps = _check_norm(sp["norm"])
@@ -270,8 +276,20 @@ class Plan:
         gate = None
         if se is not None or drop_p > 0.0:
             gate = self._gate_buffers(odims, cout, se, drop_p)
-        tape.append(Rec("inact", dict(y=y, stats=stats, eps=eps, res=residual, out=out, slope=slope, gate=gate)))
+        drop = None
+        if p_drop != 0.0:
+            # channel dropout in front of the InstanceNorm = the norm with eps * (1-p)^2 for the kept (n, c) planes and rstd = 0 for
+            # the dropped ones (rx_instnorm_stats_mask): no pass over y, forward or backward.  keep: this step's draw (torch RNG, on
+            # the device, forward order); eps_now / active follow net.training (_forward_pre).
+            drop = dict(p=p_drop, keep=torch.ones((self.B, cout), dtype=torch.float32, device=self.device), eps=eps,
+                        eps_now=eps, active=False)
+            self._drops.append(drop)
+        tape.append(Rec("inact", dict(y=y, stats=stats, eps=eps, res=residual, out=out, slope=slope, gate=gate, drop=drop)))
         return out
+
+    def _draw_dropout(self, d):
+        """this step's kept (n, c) planes of one dropout layer: 1 / 0, in place (bernoulli(1 - p) as torch's feature dropout)"""
+        d["keep"].bernoulli_(1.0 - d["p"])
 
     def _gate_buffers(self, odims, c, se, drop_p):
         """SqueezeExcite / DropPath state of one residual block (csrc/rx_se.hip): the fc parameters are read raw (fp32),
@@ -308,6 +326,17 @@ class Plan:
             return None
         return dict(w1=se["fc1"].weight, b1=se["fc1"].bias, w2=se["fc2"].weight, b2=se["fc2"].bias, rd=se["rd"],
                     keep_x=se["keep_x"])
+
+    @staticmethod
+    def _eps_now(ia):
+        d = ia.get("drop")
+        return d["eps_now"] if d is not None else ia["eps"]
+
+    @staticmethod
+    def _mask_dropped(ia):
+        d = ia.get("drop")
+        if d is not None and d["active"]:
+            ops.instnorm_stats_mask(ia["stats"], d["keep"])
 
     def _draw_path_scale(self, g):
         """DropPath: per-sample bernoulli(keep)/keep in training, None (identity) in eval"""
@@ -505,7 +534,8 @@ class Plan:
                         st = a.get("stats_to")
                         if st is not None:
                             ops.conv3d_fwd_stats(a["x"].act, a["pk"]["w_fwd"], a["b"], a["y"].act, a["kernel"], a["stride"],
-                                                 st["stats"], st["eps"])
+                                                 st["stats"], P._eps_now(st))
+                            P._mask_dropped(st)
                         else:
                             ops.conv3d_fwd(a["x"].act, a["pk"]["w_fwd"], a["b"], a["y"].act, a["kernel"], a["stride"])
                     f.append(cstep)
@@ -534,16 +564,22 @@ class Plan:
                         head = a.get("head_to")
                         if head is not None:
                             if not a.get("stats_done"):
-                                ops.instnorm_stats(a["y"].act, a["stats"], a["eps"])
+                                ops.instnorm_stats(a["y"].act, a["stats"], P._eps_now(a))
+                                P._mask_dropped(a)
                             ops.instnorm_act_head_fwd(a["y"].act, a["stats"], a["out"].act, head["w"].view(head["k"], -1), head["b"],
                                                       head["out"], head["act"] if P._apply_act else _l.RX_ACT_NONE, a["slope"])
                             return
                         pool = a.get("pool_to")
                         if pool is not None:
                             if not a.get("stats_done"):
-                                ops.instnorm_stats(a["y"].act, a["stats"], a["eps"])
+                                ops.instnorm_stats(a["y"].act, a["stats"], P._eps_now(a))
+                                P._mask_dropped(a)
                             ops.instnorm_act_pool_fwd(a["y"].act, a["stats"], a["out"].act, pool["y"].act, pool["stride"], a["slope"], res)
                         elif a.get("stats_done"):     # the producing conv left (mean, rstd) behind
+                            ops.instnorm_act_fwd(a["y"].act, a["stats"], a["out"].act, a["slope"], res)
+                        elif a["drop"] is not None and a["drop"]["active"]:     # statistics, dropped planes, apply
+                            ops.instnorm_stats(a["y"].act, a["stats"], P._eps_now(a))
+                            P._mask_dropped(a)
                             ops.instnorm_act_fwd(a["y"].act, a["stats"], a["out"].act, a["slope"], res)
                         else:
                             ops.instnorm_fwd(a["y"].act, a["stats"], a["out"].act, a["slope"], res, a["eps"])
@@ -993,7 +1029,7 @@ class Plan:
     def _graphs_on(self):
         # (needs_grad plans only: an inference plan re-packs nothing and has no backward list worth capturing)
         return (self.use_graphs and self.device.type == "cuda" and self.needs_grad
-                and self.grad_sync is None and ops._PROF is None)
+                and self.grad_sync is None and ops._PROF is None and not self._drops)
 
     def _param_ptrs(self):
         return tuple(p.data_ptr() for p in self.params)
@@ -1030,6 +1066,12 @@ class Plan:
             self._raw_seen = ev
         for g in self._gates:                               # DropPath: this step's per-sample factors (torch RNG)
             g["scale_now"] = self._draw_path_scale(g)
+        training = bool(self.net.training)
+        for d in self._drops:                               # channel dropout: this step's kept planes, in forward order
+            d["active"] = training
+            d["eps_now"] = d["eps"] * (1.0 - d["p"]) ** 2 if training else d["eps"]
+            if training:
+                self._draw_dropout(d)
 
     def _forward_body(self, force_packs):
         self.refresh_packs(force=force_packs)
@@ -1070,7 +1112,7 @@ class Plan:
             self._x_static.copy_(x)                 # the program reads a fixed address
             self._x = self._x_static.unsqueeze(2) if self.two_d else self._x_static
             stale = bool(self._packs_stale())
-            dropping = any(g["scale_now"] is not None for g in self._gates)
+            dropping = any(g["scale_now"] is not None for g in self._gates) or any(d["active"] for d in self._drops)
             # one program per launch-list VARIANT: with / without the weight re-pack, with / without DropPath factors
             key = ("f", apply_act, stale, dropping, self.overlap_wgrad)
             _, replayed = self._programmed(key, lambda: self._forward_body(force_packs=stale))

@@ -96,6 +96,12 @@ CASES = {
     "no_stem_plain": dict(patch=(16, 16, 16), batch=2, in_channels=1, tasks=TASKS_SIGMOID_SHEET, autoconfigure=False,
                           model_config=_manual(do_stem=False, basic_encoder_block="ResidualBlock"), seed=11, data_seed=1, train=True,
                           full_grads=("shared_encoder.stages.0.0.convs.0.conv.weight", "sheet.transpconvs.1.weight")),
+    # channel dropout (dropout_op_kwargs p > 0, build_network_from_config.py:169-170; nn.Dropout3d between conv and norm in the
+    # stem, every block's conv1 and the decoder convs): the fixture carries the masks the reference drew (dropmask.NNN)
+    "dropout": dict(patch=(16, 16, 16), batch=2, in_channels=1, tasks=TASKS_SIGMOID_SHEET, autoconfigure=False,
+                    model_config=_manual(dropout_op_kwargs={"p": 0.25}), seed=11, data_seed=1, train=True,
+                    full_grads=("stages.0.blocks.0.conv1.conv.weight", "stages.1.blocks.1.conv1.conv.weight",
+                                "sheet.stages.1.convs.0.conv.weight")),
 }
 
 # Cases WITHOUT a reference fixture -- PARITY UNPINNED: SqueezeExcite / DropPath live in the un-vendored

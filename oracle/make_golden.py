@@ -47,10 +47,21 @@ def main():
         net = ref_shim.build_reference_network(mgr)
         x, targets = synthetic_batch(c["batch"], c["in_channels"], c["patch"], c["tasks"], c["data_seed"])
         net.train()
+        # channel dropout (dropout_op_kwargs p > 0): the reference draws its masks from the global CPU generator during this
+        # forward; the fixture keeps them (kept (n, c) planes, in execution order) so that the engine can replay the same step
+        drop_masks, hooks = [], []
+        for mod in net.modules():
+            if isinstance(mod, (torch.nn.Dropout3d, torch.nn.Dropout2d)) and mod.p > 0:
+                hooks.append(mod.register_forward_hook(
+                    lambda m, inp, outp: drop_masks.append((outp.detach().flatten(2).abs().amax(2) > 0).float().numpy())))
         out = net(x)
+        for h in hooks:
+            h.remove()
         loss = reference_loss(ref_losses, out, targets, c["tasks"])
         loss.backward()
         arrays = {"x": x.numpy(), "loss": np.float64(loss.item())}
+        for i, mk in enumerate(drop_masks):
+            arrays[f"dropmask.{i:03d}"] = mk
         for k, v in targets.items():
             arrays[f"target.{k}"] = v.numpy()
         for k, v in out.items():

@@ -39,3 +39,24 @@ def rel_l2(a, b):
 
 def quiet():
     return contextlib.redirect_stdout(io.StringIO())
+
+
+@contextlib.contextmanager
+def forced_dropout(masks):
+    """replay channel-dropout masks (a golden fixture's `dropmask.NNN`, kept (n, c) planes in execution order) on the engine:
+    the i-th dropout layer of a plan keeps masks[i] instead of drawing from torch's generator"""
+    from mt3d_amd.engine import plan as plan_mod
+    orig = plan_mod.Plan._draw_dropout
+
+    def draw(self, d):
+        i = next(j for j, e in enumerate(self._drops) if e is d)
+        d["keep"].copy_(torch.as_tensor(masks[i]))
+    plan_mod.Plan._draw_dropout = draw
+    try:
+        yield
+    finally:
+        plan_mod.Plan._draw_dropout = orig
+
+
+def golden_dropout_masks(g):
+    return [g[k] for k in sorted(g) if k.startswith("dropmask.")]

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 import resenc_oracle as oracle
 from golden_cases import CASES
-from helpers import load_golden, rel_l2
+from helpers import forced_dropout, golden_dropout_masks, load_golden, rel_l2
 
 
 @pytest.fixture(scope="module")
@@ -43,7 +43,12 @@ def test_fp32_matches_reference_golden(NetworkFromConfig, case):
     x = torch.from_numpy(g["x"]).cuda()
     targets = {k[len("target."):]: torch.from_numpy(v).cuda() for k, v in g.items() if k.startswith("target.")}
     net.train()
-    out = net(x)
+    masks = golden_dropout_masks(g)                 # channel dropout: the planes the reference kept in this very step
+    with forced_dropout(masks):
+        out = net(x)
+    if masks:
+        plan = next(iter(net._plans.values()))
+        assert len(plan._drops) == len(masks) and any((m == 0).any() for m in masks)
     assert list(out.keys()) == list(c["tasks"].keys())
     for k, v in out.items():
         ref = torch.from_numpy(g[f"logits.{k}"])
@@ -431,7 +436,7 @@ def test_torch_compile_wrapper_trains_and_keeps_reference_checkpoint_keys(Networ
     assert all(v.shape == bare_logits[k].shape for k, v in ev.items())
 
 
-@pytest.mark.parametrize("variant", ["two_heads_bf16", "se_droppath_fp32"])
+@pytest.mark.parametrize("variant", ["two_heads_bf16", "se_droppath_fp32", "dropout_bf16"])
 def test_launch_program_replay_is_bit_identical_to_eager(NetworkFromConfig, monkeypatch, variant):
     """launch programs (default on, include/rxunet.h "launch programs"): after two eager passes every forward / backward
     launch list is recorded by the library while it executes and then replayed from C.  Same launches, same streams,
@@ -444,6 +449,9 @@ def test_launch_program_replay_is_bit_identical_to_eager(NetworkFromConfig, monk
     if variant == "two_heads_bf16":
         c = CASES["auto16_2head"]
         patch, tasks, cin, batch, auto, mc, dtype = c["patch"], c["tasks"], c["in_channels"], c["batch"], True, {}, torch.bfloat16
+    elif variant == "dropout_bf16":       # channel dropout: new masks every step (device generator), read by the program from a fixed buffer
+        patch, tasks, cin, batch, auto, dtype = (32, 32, 32), TASKS_2HEAD, 1, 2, True, torch.bfloat16
+        mc = {"dropout_op_kwargs": {"p": 0.2}}
     else:
         patch, tasks, cin, batch, auto, dtype = (16, 16, 16), TASKS_2HEAD, 1, 2, False, None
         mc = _manual(squeeze_excitation=True, stochastic_depth_p=0.3)
@@ -491,3 +499,89 @@ def test_launch_program_replay_is_bit_identical_to_eager(NetworkFromConfig, monk
             assert torch.equal(a[k], b[k]), k
     for n in p_e:
         assert torch.equal(p_e[n], p_p[n]), n
+
+
+def test_channel_dropout_on_the_fused_paths(NetworkFromConfig):
+    """dropout_op_kwargs p > 0 at a size where the statistics come out of conv epilogues, the head is fused into the layer below
+    it and the InstanceNorm backward sums ride in data-gradient epilogues (bf16, 64^3): with FORCED masks the planes the masks
+    drop are exactly zero after the norm, a bf16 step agrees with the fp32 step on the same masks, the weight gradient of a
+    channel dropped in every sample is exactly zero, repeated steps are bit-identical; eval ignores the masks; free-running
+    masks keep ~(1 - p) of the planes and change from step to step."""
+    from mt3d_amd.engine import plan as plan_mod
+    p = 0.3
+    patch, tasks = (64, 64, 64), {"sheet": {"channels": 1, "activation": "none", "loss_fn": "BCEDiceLoss",
+                                            "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
+    mgr = oracle.make_mgr(patch, tasks, 1, 2, True, {"dropout_op_kwargs": {"p": p}})
+    torch.manual_seed(0)
+    net = NetworkFromConfig(mgr).cuda()
+    x, t = oracle.synthetic_batch(2, 1, patch, tasks, 3)
+    x, t = x.cuda(), {k: v.cuda() for k, v in t.items()}
+    gen = torch.Generator().manual_seed(5)
+    masks = {}
+
+    def draw(self, d):
+        i = next(j for j, e in enumerate(self._drops) if e is d)
+        if i not in masks:
+            mk = torch.bernoulli(torch.full(tuple(d["keep"].shape), 1 - p), generator=gen)
+            if i == 1:
+                mk[:, 3] = 0            # one channel of the first block's conv1 dropped in BOTH samples
+            masks[i] = mk
+        d["keep"].copy_(masks[i])
+    orig = plan_mod.Plan._draw_dropout
+    plan_mod.Plan._draw_dropout = draw
+    try:
+        res = {}
+        for dt in (torch.float32, torch.bfloat16):
+            net.compute_dtype = dt
+            runs = []
+            for _ in range(3 if dt == torch.bfloat16 else 1):       # (bf16: passes 3.. are program replays)
+                net.zero_grad(set_to_none=True)
+                out = net(x)
+                loss = oracle.train_loss(out, t, tasks)
+                loss.backward()
+                runs.append((out["sheet"].detach().clone(), {n: q.grad.detach().clone() for n, q in net.named_parameters() if q.grad is not None}))
+            for o, g in runs[1:]:
+                assert torch.equal(o, runs[0][0]) and all(torch.equal(g[n], runs[0][1][n]) for n in g)
+            res[dt] = runs[0]
+            plan = [pl for pl in net._plans.values() if pl.dtype == dt and pl.needs_grad][0]
+            assert len(plan._drops) == len(masks)
+            # the activations after a dropped plane's InstanceNorm are exactly zero
+            inacts = [r for tape in [plan.enc_tape] + plan.dec_tapes for r in tape if r.kind == "inact" and r.a["drop"] is not None]
+            for i, r in enumerate(inacts):
+                a = r.a["out"].act.tensor().float()          # (N, Z, Y, X, C)
+                dropped = masks[i] == 0
+                if dropped.any():
+                    planes = a.abs().amax(dim=(1, 2, 3))      # (N, C)
+                    assert (planes[dropped.cuda()] == 0).all(), i
+                    assert (planes[~dropped.cuda()] > 0).all(), i
+        lo, hi = res[torch.bfloat16], res[torch.float32]
+        assert rel_l2(lo[0].cpu(), hi[0].cpu()) < 4e-2
+        wname = "shared_encoder.stages.0.blocks.0.conv1.conv.weight"
+        assert (hi[1][wname][3] == 0).all() and (lo[1][wname][3] == 0).all() and hi[1][wname].abs().sum() > 0
+        for n in hi[1]:
+            a_, b_ = lo[1][n].double().flatten(), hi[1][n].double().flatten()
+            if b_.norm() > 1e-6 and not n.endswith(".conv.bias"):
+                # direction only (bf16 flips ~1 % of the LeakyReLU masks per layer; the deep stages of a random-init net carry
+                # gradients of norm 1e-4 that are mostly that noise: 0.79 seen at stage 3)
+                assert (a_ @ b_ / (a_.norm() * b_.norm())).item() > (0.9 if ".stages.0." in n or ".stem." in n else 0.6), n
+    finally:
+        plan_mod.Plan._draw_dropout = orig
+    # eval: identity (same output whatever the keep buffers hold)
+    net.eval()
+    with torch.no_grad():
+        e1 = net(x)["sheet"].clone()
+        for pl in net._plans.values():
+            for d in pl._drops:
+                d["keep"].zero_()
+        e2 = net(x)["sheet"].clone()
+    assert torch.equal(e1, e2) and e1.abs().sum() > 0
+    # free-running masks: ~(1 - p) kept, different from step to step
+    net.train()
+    torch.manual_seed(9)
+    fr = []
+    for _ in range(2):
+        net(x)
+        plan = [pl for pl in net._plans.values() if pl.dtype == torch.bfloat16 and pl.needs_grad][0]
+        fr.append(torch.cat([d["keep"].flatten() for d in plan._drops]).clone())
+    assert not torch.equal(fr[0], fr[1]) and set(fr[0].unique().tolist()) <= {0.0, 1.0}
+    assert abs(fr[0].mean().item() - (1 - p)) < 0.05

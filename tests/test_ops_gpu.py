@@ -211,6 +211,37 @@ def test_instnorm_lrelu_residual(ops, dtype, c, dims):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c,dims", [(32, (8, 8, 8)), (64, (5, 12, 16))])      # single-launch range / three-launch path
+def test_channel_dropout_as_masked_statistics(ops, dtype, c, dims):
+    """nn.Dropout3d between conv and InstanceNorm (simple_conv_blocks.py:57-66) == the norm computed with eps * (1-p)^2 plus
+    rx_instnorm_stats_mask (rstd = 0 for the dropped planes): forward and backward against fp64 torch autograd of
+    leaky_relu(instance_norm(y * mask / (1 - p)))."""
+    n, p, eps, slope = 3, 0.3, 1e-5, 0.01
+    yv = rnd((n, c, *dims), dtype, seed=1) + 0.2
+    gv = rnd((n, c, *dims), dtype, seed=2, scale=0.1)
+    keep = torch.bernoulli(torch.full((n, c), 1 - p), generator=torch.Generator().manual_seed(3))
+    keep[0, 0], keep[1, 1] = 0.0, 1.0
+    yr = yv.clone().requires_grad_(True)
+    ref = F.leaky_relu(F.instance_norm(yr * (keep.double() / (1 - p)).view(n, c, 1, 1, 1), eps=eps), slope)
+    ref.backward(gv)
+    ya, ga = to_act(ops, yv, dtype), to_act(ops, gv, dtype)
+    out, dy = ops.Act.empty(n, *dims, c, dtype), ops.Act.empty(n, *dims, c, dtype)
+    stats = torch.empty((n, c, 2), device="cuda")
+    ops.instnorm_stats(ya, stats, eps * (1 - p) ** 2)
+    ops.instnorm_stats_mask(stats, keep.cuda())
+    ops.instnorm_act_fwd(ya, stats, out, slope)
+    ops.instnorm_act_bwd(ga, ya, stats, None, dy, slope)
+    torch.cuda.synchronize()
+    assert (stats[..., 1].cpu()[keep == 0] == 0).all() and (stats[..., 1].cpu()[keep == 1] > 0).all()
+    o = out.to_ncdhw().double().cpu()
+    assert (o[keep == 0] == 0).all()
+    assert rel(o, ref.detach()) < TOL[dtype]
+    d = dy.to_ncdhw().double().cpu()
+    assert (d[keep == 0] == 0).all()
+    assert rel(d, yr.grad) < 5 * TOL[dtype]          # (cancellation in the norm backward + the output rounding)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("s", [(2, 2, 2), (1, 2, 2)])
 def test_avgpool(ops, dtype, s):
     n, c, dims = 2, 64, (4, 6, 8)

@@ -30,7 +30,10 @@ def test_state_dict_and_forward_backward_equal(case):
     _, ref_losses = ref_shim.import_reference()
     x, targets = oracle.synthetic_batch(c["batch"], c["in_channels"], c["patch"], c["tasks"], c["data_seed"])
     ref.train(); mine.train()
-    o_r, o_m = ref(x), mine(x)
+    torch.manual_seed(77)                              # (channel dropout draws its masks from the global generator)
+    o_r = ref(x)
+    torch.manual_seed(77)
+    o_m = mine(x)
     for k in o_r:
         assert torch.equal(o_r[k], o_m[k]), k          # identical op sequence -> identical bits
     # loss restatement vs the reference's loss classes

@@ -75,9 +75,12 @@ def test_no_cpu_fallback_and_loud_rejections():
     mgr = oracle.make_mgr((16, 16, 16), {"a": {"channels": 1}}, autoconfigure=False, model_config={})
     with pytest.raises(ValueError):
         NetworkFromConfig(mgr)
-    mgr = oracle.make_mgr((16, 16, 16), {"a": {"channels": 1}}, model_config={"dropout_op_kwargs": {"p": 0.5}})
-    with pytest.raises(UnsupportedConfig):
+    mgr = oracle.make_mgr((16, 16, 16), {"a": {"channels": 1}}, model_config={"dropout_op_kwargs": {"p": 1.0}})
+    with pytest.raises(UnsupportedConfig):          # (0 < p < 1 runs natively: tests/golden/dropout.npz)
         Plan(NetworkFromConfig(mgr).to("meta"), (1, 1, 16, 16, 16), torch.float32, "meta", True)
+    mgr = oracle.make_mgr((16, 16, 16), {"a": {"channels": 1}}, model_config={"dropout_op_kwargs": {"p": 0.5}})
+    plan = Plan(NetworkFromConfig(mgr).to("meta"), (1, 1, 16, 16, 16), torch.float32, "meta", True)
+    assert len(plan._drops) >= 5 and all(d["keep"].shape[0] == 1 for d in plan._drops)
 
 
 def test_yaml_string_blocks_do_not_crash_like_the_reference():
