@@ -107,7 +107,6 @@ class Plan:
         if self.two_d:
             spatial = (1,) + spatial         # a 2-D net is the 3-D engine with a unit Z axis
         self.B, self.Cin, self.spatial = B, Cin, spatial
-        self.chan_mult = 16 if dtype == torch.float32 else 32
 
         self.params: List[nn.Parameter] = []
         self._pidx: Dict[int, int] = {}
@@ -143,6 +142,16 @@ class Plan:
         self._pack_groups = None                  # [(entries, event slot)] in first-use order (static per plan)
         self._gates: List[dict] = []              # SqueezeExcite / DropPath state of every gated block, forward order
         self._drops: List[dict] = []              # channel-dropout layers (dropout_op_kwargs p > 0), forward order
+        # Channel counts that are not a multiple of the kernels' K tile (features_per_stage is free in the reference,
+        # build_network_from_config.py:85-148): every activation buffer is PADDED to the next multiple, and each parameter that
+        # touches a padded extent gets a zero-padded fp32 SHADOW that the kernels read instead (refreshed from the real
+        # parameter in _forward_pre; zero weights / bias keep the padding channels exactly 0 through conv, InstanceNorm,
+        # LeakyReLU, pool, transposed conv and head); its gradient is produced padded and sliced back in _backward_finish.
+        # No kernel knows about it.  (Cost: the padded FLOPs and ~3 small torch copies per padded parameter and step.)
+        self._shadows: List[dict] = []
+        self._shadow_of: Dict[int, dict] = {}
+        self._pad_idx: Dict[int, dict] = {}       # parameter index -> shadow entry
+        self._pad_done: List[int] = []
         # Launch programs (default on; RX_PROGRAMS=0 = one ctypes call per launch): the forward / backward lists are static, so
         # after two eager passes each is RECORDED once by the library while it executes (rx_prog_begin/end) and every later
         # step replays it with one C call -- the same launches on the same two streams, without ~700 host-language calls
@@ -217,11 +226,37 @@ class Plan:
         self.packs.append(ent)
         return ent
 
-    def _chk_channels(self, *cs):
-        for c in cs:
-            if c % self.chan_mult:
-                raise UnsupportedConfig(f"channel count {c} is not a multiple of {self.chan_mult} "
-                                        f"(MFMA K tile of the {self.dtype} kernels)")
+    def _cp(self, c):
+        """channel count of the BUFFER that holds c channels (next multiple of the kernels' K tile)"""
+        return (c + 31) // 32 * 32      # (output channels: 32 in every compute type; the fp32 kernels' K tile is 16)
+
+    def _shadow(self, p, shape, pairs):
+        """the tensor the kernels read for parameter p: p itself when nothing is padded, else a persistent zero tensor of `shape`
+        whose index ranges `pairs` = [(dst index, src index)] mirror p (see self._shadows)"""
+        if p is None or tuple(shape) == tuple(p.shape):
+            return p
+        ent = self._shadow_of.get(id(p))
+        if ent is None:
+            sh = torch.zeros(tuple(shape), dtype=p.dtype, device=self.device)
+            self.bytes_alloc += sh.numel() * sh.element_size()
+            ent = dict(param=p, sh=sh, pairs=list(pairs), seen=None, gpad=None)
+            self._shadows.append(ent)
+            self._shadow_of[id(p)] = ent
+            self._pad_idx[self._param(p)] = ent
+        elif tuple(ent["sh"].shape) != tuple(shape):
+            raise UnsupportedConfig("one parameter read with two different padded shapes")
+        return ent["sh"]
+
+    def _refresh_shadows(self):
+        epoch = getattr(self.net, "_weights_epoch", 0)
+        for e in self._shadows:
+            q = e["param"]
+            tag = (q._version, q.data_ptr(), epoch)
+            if e["seen"] != tag:
+                src = q.detach()
+                for dst, sidx in e["pairs"]:
+                    e["sh"][dst].copy_(src[sidx])
+                e["seen"] = tag
 
     @staticmethod
     def _out_dims(dims, kernel, stride):
@@ -254,34 +289,47 @@ class Plan:
             if s not in (1, 2):
                 raise UnsupportedConfig(f"stride {s} has no HIP kernel (1 or 2 per axis)")
         cin, cout = conv.in_channels, conv.out_channels
+        cout_p = self._cp(cout)
         first_of_net = first_of_net or x is None      # x is None: the layer reads the NCDHW image (the stem; without one, the first block)
         in_dims = x.act.dims[1:] if not first_of_net else self.spatial
         odims = self._out_dims(in_dims, kernel, stride)
-        y = self._new(odims, cout, f"y:{len(tape)}")
-        stats = torch.empty((self.B, cout, 2), dtype=torch.float32, device=self.device)
+        y = self._new(odims, cout_p, f"y:{len(tape)}")
+        stats = torch.empty((self.B, cout_p, 2), dtype=torch.float32, device=self.device)
         if out is None:
-            out = self._new(odims, cout, f"a:{len(tape)}")
+            out = self._new(odims, cout_p, f"a:{len(tape)}")
+        elif out.act.c != cout_p:
+            raise RuntimeError("plan bug: destination of a layer has the wrong channel extent")
         widx = self._param(conv.weight)
         bidx = self._param(conv.bias) if conv.bias is not None else None
+        kshape = tuple(conv.weight.shape[2:])
+        b_k = self._shadow(conv.bias, (cout_p,), [((slice(0, cout),), (slice(None),))])
         if first_of_net:
             if cin > 8 or any(s != 1 for s in stride):
                 raise UnsupportedConfig("the first convolution reads the NCDHW image: needs in_channels <= 8, stride 1")
-            self._chk_channels(cout)
-            tape.append(Rec("stem", dict(y=y, w=conv.weight, b=conv.bias, widx=widx, bidx=bidx, kernel=kernel)))
+            if cout_p > 64:
+                raise UnsupportedConfig(f"the first convolution writes {cout} channels (its weight-gradient kernel holds <= 64)")
+            w_k = self._shadow(conv.weight, (cout_p, cin, *kshape), [((slice(0, cout),), (slice(None),))])
+            tape.append(Rec("stem", dict(y=y, w=w_k, b=b_k, widx=widx, bidx=bidx, kernel=kernel)))
         else:
-            self._chk_channels(cin, cout)
-            pk = self._pack(conv.weight, "conv")
-            tape.append(Rec("conv", dict(x=x, y=y, pk=pk, b=conv.bias, widx=widx, bidx=bidx, kernel=kernel,
+            # input-channel ranges of the weight -> where they sit in the (padded) input buffer; a decoder conv reads the concat
+            # [upsampled C | skip C], whose halves are padded separately
+            segs = getattr(x, "segs", None) or [(0, cin, 0)]
+            if sum(L for _, L, _ in segs) != cin:
+                raise RuntimeError("plan bug: input-channel segments do not add up")
+            w_k = self._shadow(conv.weight, (cout_p, x.act.c, *kshape),
+                               [((slice(0, cout), slice(d, d + L)), (slice(None), slice(s0, s0 + L))) for s0, L, d in segs])
+            pk = self._pack(w_k, "conv")
+            tape.append(Rec("conv", dict(x=x, y=y, pk=pk, b=b_k, widx=widx, bidx=bidx, kernel=kernel,
                                          stride=stride)))
         gate = None
         if se is not None or drop_p > 0.0:
-            gate = self._gate_buffers(odims, cout, se, drop_p)
+            gate = self._gate_buffers(odims, cout_p, se, drop_p)
         drop = None
         if p_drop != 0.0:
             # channel dropout in front of the InstanceNorm = the norm with eps * (1-p)^2 for the kept (n, c) planes and rstd = 0 for
             # the dropped ones (rx_instnorm_stats_mask): no pass over y, forward or backward.  keep: this step's draw (torch RNG, on
             # the device, forward order); eps_now / active follow net.training (_forward_pre).
-            drop = dict(p=p_drop, keep=torch.ones((self.B, cout), dtype=torch.float32, device=self.device), eps=eps,
+            drop = dict(p=p_drop, keep=torch.ones((self.B, cout_p), dtype=torch.float32, device=self.device), eps=eps,
                         eps_now=eps, active=False)
             self._drops.append(drop)
         tape.append(Rec("inact", dict(y=y, stats=stats, eps=eps, res=residual, out=out, slope=slope, gate=gate, drop=drop)))
@@ -306,7 +354,13 @@ class Plan:
             rd = se.fc1.out_channels
             if rd > 64:
                 raise UnsupportedConfig(f"SqueezeExcite with {rd} reduction channels (the gate kernel holds <= 64)")
-            g["se"] = dict(fc1=se.fc1, fc2=se.fc2, rd=rd, keep_x=keep_x,
+            c_real = se.fc2.out_channels
+            ones = tuple(se.fc1.weight.shape[2:])
+            g["se"] = dict(rd=rd, keep_x=keep_x,
+                           w1=self._shadow(se.fc1.weight, (rd, c, *ones), [((slice(None), slice(0, c_real)), (slice(None), slice(None)))]),
+                           b1=se.fc1.bias,
+                           w2=self._shadow(se.fc2.weight, (c, rd, *ones), [((slice(0, c_real),), (slice(None),))]),
+                           b2=self._shadow(se.fc2.bias, (c,), [((slice(0, c_real),), (slice(None),))]),
                            idx=[self._param(se.fc1.weight), self._param(se.fc1.bias), self._param(se.fc2.weight),
                                 self._param(se.fc2.bias)])
             g["pooled"] = torch.empty((self.B, L, c), **f32)
@@ -324,8 +378,7 @@ class Plan:
         se = g["se"]
         if se is None:
             return None
-        return dict(w1=se["fc1"].weight, b1=se["fc1"].bias, w2=se["fc2"].weight, b2=se["fc2"].bias, rd=se["rd"],
-                    keep_x=se["keep_x"])
+        return dict(w1=se["w1"], b1=se["b1"], w2=se["w2"], b2=se["b2"], rd=se["rd"], keep_x=se["keep_x"])
 
     @staticmethod
     def _eps_now(ia):
@@ -382,6 +435,7 @@ class Plan:
         tasks = list(net.task_decoders.keys())
         n_st = len(enc.stages)
         feats = list(enc.output_channels)
+        featsp = [self._cp(f) for f in feats]
 
         # ---- spatial size per encoder stage
         dims = [None] * n_st
@@ -399,7 +453,9 @@ class Plan:
             row = []
             for j in range(n_st - 1):
                 es = n_st - 2 - j
-                row.append(self._new_cat(dims[es], feats[es], f"cat{d}.{j}"))
+                cat = self._new_cat(dims[es], featsp[es], f"cat{d}.{j}")
+                cat.segs = [(0, feats[es], 0), (feats[es], feats[es], featsp[es])]     # (weight range start, length, buffer start)
+                row.append(cat)
             cats.append(row)
 
         def skip_home(es):
@@ -407,7 +463,7 @@ class Plan:
             if es == n_st - 1 or not tasks:
                 return None
             cat = cats[0][n_st - 2 - es]
-            c = feats[es]
+            c = featsp[es]
             return AT(cat.act.slice(c, c), f"skip{es}")
 
         # ---- encoder
@@ -441,18 +497,23 @@ class Plan:
             low = skips[-1]
             for j in range(n_st - 1):
                 es = n_st - 2 - j
-                c = feats[es]
+                c = featsp[es]
                 cat = cats[d][j]
                 up = AT(cat.act.slice(0, c), f"up{d}.{j}")
                 tconv = dec.transpconvs[j]
                 stride = self._k3(tconv.stride)
                 if list(tconv.kernel_size) != list(tconv.stride):
                     raise UnsupportedConfig("ConvTranspose with kernel != stride")
-                self._chk_channels(tconv.in_channels, tconv.out_channels)
-                pk = self._pack(tconv.weight, "convT")
+                ti, to = tconv.in_channels, tconv.out_channels
+                if self._cp(ti) != low.act.c or self._cp(to) != c:
+                    raise RuntimeError("plan bug: transposed-conv channel extents")
+                w_k = self._shadow(tconv.weight, (low.act.c, c, *tconv.weight.shape[2:]),
+                                   [((slice(0, ti), slice(0, to)), (slice(None), slice(None)))])
+                b_k = self._shadow(tconv.bias, (c,), [((slice(0, to),), (slice(None),))])
+                pk = self._pack(w_k, "convT")
                 widx = self._param(tconv.weight)
                 bidx = self._param(tconv.bias) if tconv.bias is not None else None
-                tape.append(Rec("convT", dict(x=low, y=up, pk=pk, b=tconv.bias, widx=widx, bidx=bidx, stride=stride,
+                tape.append(Rec("convT", dict(x=low, y=up, pk=pk, b=b_k, widx=widx, bidx=bidx, stride=stride,
                                               cat=cat)))
                 if d > 0:
                     dst = AT(cat.act.slice(c, c), f"skipcopy{d}.{j}")
@@ -478,7 +539,9 @@ class Plan:
                 act_code = _l.RX_ACT_SIGMOID
             elif isinstance(act_mod, nn.Softmax):
                 act_code = _l.RX_ACT_SOFTMAX
-            tape.append(Rec("head", dict(x=low, w=head.weight, b=head.bias, widx=self._param(head.weight),
+            hw_k = self._shadow(head.weight, (k, low.act.c, *head.weight.shape[2:]),
+                                [((slice(None), slice(0, head.in_channels)), (slice(None), slice(None)))])
+            tape.append(Rec("head", dict(x=low, w=hw_k, b=head.bias, widx=self._param(head.weight),
                                          bidx=self._param(head.bias), k=k, name=name, out=out, act=act_code)))
 
         self._gen_forward()
@@ -626,6 +689,12 @@ class Plan:
             # a FRESH tensor every backward (autograd may keep / accumulate into what we return); a gradient
             # synchroniser may hand out views of its flat buckets instead (engine/ddp.py)
             sync = P.grad_sync
+            ent = P._pad_idx.get(idx)
+            if ent is not None:                 # padded parameter: the kernels write the padded gradient, _backward_finish slices it
+                if ent["gpad"] is None:
+                    ent["gpad"] = torch.empty(tuple(ent["sh"].shape), dtype=torch.float32, device=P.device)
+                P._pad_done.append(idx)
+                return ent["gpad"]
             if sync is not None:
                 g = sync.alloc(idx)
             elif P._use_gstore:             # program mode: the same storage every backward (see _grad_store)
@@ -638,6 +707,8 @@ class Plan:
         skip = set(filter(None, os.environ.get("RX_SKIP", "").split(",")))     # TIMING ABLATIONS ONLY (wrong results)
 
         def done(idx):
+            if idx in P._pad_idx:               # completed (and announced to a gradient synchroniser) in _backward_finish
+                return
             if P._recording is not None:        # while a program is recorded: where in the command list the gradient is complete
                 P._marks.append((len(P._recording), idx, P._on_side))
             if P.grad_sync is not None:
@@ -1066,6 +1137,8 @@ class Plan:
             self._raw_seen = ev
         for g in self._gates:                               # DropPath: this step's per-sample factors (torch RNG)
             g["scale_now"] = self._draw_path_scale(g)
+        if self._shadows:                                   # padded channel extents: zero-padded copies of the parameters
+            self._refresh_shadows()
         training = bool(self.net.training)
         for d in self._drops:                               # channel dropout: this step's kept planes, in forward order
             d["active"] = training
@@ -1137,6 +1210,24 @@ class Plan:
 
     def _backward_finish(self):
         grads = self._grads
+        if self._pad_idx:
+            # padded parameters: slice the real gradient out of the padded one (main stream, after the join of the side stream)
+            sync = self.grad_sync
+            for idx in sorted(set(self._pad_done)):
+                ent = self._pad_idx[idx]
+                q = ent["param"]
+                if sync is not None:
+                    real = sync.alloc(idx)
+                elif self._use_gstore:
+                    real = self._gviews[idx]
+                else:
+                    real = torch.empty_like(q, memory_format=torch.contiguous_format)
+                for dst, sidx in ent["pairs"]:
+                    real[sidx].copy_(ent["gpad"][dst])
+                grads[idx] = real
+                if sync is not None:
+                    sync.ready(idx)
+            self._pad_done = []
         if self.grad_sync is not None:
             self.grad_sync.finish()
             if not self.grad_sync.returns_grads:    # a local micro-batch of an accumulation window: the synchroniser carries
@@ -1193,6 +1284,8 @@ class Plan:
             key = ("b", tuple(sorted(self._dlogits)), id(sync) if sync is not None else 0, self.overlap_wgrad)
             st, replayed = self._programmed(key, self._backward_body,
                                             segments=self._replay_backward_segments if sync is not None else None)
+            if replayed:
+                self._pad_done = [idx for idx in set(self.grad_order) if idx in self._pad_idx]
             if replayed and sync is None:
                 for idx in set(self.grad_order):
                     self._grads[idx] = self._gviews[idx]

@@ -48,7 +48,11 @@ class StreamedOptimizerStep:
         return getattr(self.opt, "grad_scale", None) is None and getattr(self.opt, "found_inf", None) is None
 
     def _train_plans(self):
-        return [p for p in getattr(self.model, "_plans", {}).values() if p.needs_grad and p.device.type == "cuda"]
+        plans = [p for p in getattr(self.model, "_plans", {}).values() if p.needs_grad and p.device.type == "cuda"]
+        if any(p._shadows for p in plans):
+            raise NotImplementedError("streamed optimizer step: plans with padded channel extents pack from shadow tensors "
+                                      "(feature counts that are not multiples of 32); use the plain step")
+        return plans
 
     def synchronize(self):
         for plan in self._train_plans():

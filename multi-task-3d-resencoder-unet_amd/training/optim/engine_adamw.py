@@ -67,7 +67,9 @@ class EngineAdamW(torch.optim.Optimizer):
     def _plan(self):
         plans = [p for p in getattr(self.model, "_plans", {}).values() if p.needs_grad and p.device.type == "cuda"] \
             if self.model is not None else []
-        return plans[0] if len(plans) == 1 else None
+        # (a plan with padded channel extents packs from zero-padded SHADOW tensors: the fused update-and-pack kernel would write
+        # un-padded layouts -- such plans take the plain update and re-pack in their next forward)
+        return plans[0] if len(plans) == 1 and not plans[0]._shadows else None
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -102,6 +102,15 @@ CASES = {
                     model_config=_manual(dropout_op_kwargs={"p": 0.25}), seed=11, data_seed=1, train=True,
                     full_grads=("stages.0.blocks.0.conv1.conv.weight", "stages.1.blocks.1.conv1.conv.weight",
                                 "sheet.stages.1.convs.0.conv.weight")),
+    # feature counts that are not a multiple of the kernels' 32-channel K tile (features_per_stage is free in the reference,
+    # build_network_from_config.py:85-148): padded buffers + zero-padded shadow parameters inside the engine; conv_bias on,
+    # 2-class softmax head, ResidualBlock decoder (its skip projection reads the padded concat too)
+    "odd_channels": dict(patch=(16, 16, 16), batch=2, in_channels=1, tasks=TASKS_SOFTMAX2_W1, autoconfigure=False,
+                         model_config=_manual(features_per_stage=[24, 48, 80], basic_decoder_block="ResidualBlock", conv_bias=True),
+                         seed=11, data_seed=1, train=True,
+                         full_grads=("stages.0.blocks.0.conv1.conv.weight", "stages.1.blocks.1.conv2.conv.weight",
+                                     "seg.stages.1.blocks.0.conv1.conv.weight", "seg.transpconvs.0.weight",
+                                     "seg.stages.1.blocks.0.skip.0.conv.weight")),
 }
 
 # Cases WITHOUT a reference fixture -- PARITY UNPINNED: SqueezeExcite / DropPath live in the un-vendored
@@ -115,6 +124,9 @@ UNPINNED_CASES = {
                                                            bottleneck_block="BottleneckBlockD",
                                                            bottleneck_channels=[32, 32, 64], squeeze_excitation=True),
                                       seed=11, data_seed=3),
+    "squeeze_excite_odd_channels": dict(patch=(16, 16, 16), batch=2, in_channels=1, tasks=TASKS_SIGMOID_SHEET, autoconfigure=False,
+                                        model_config=_manual(features_per_stage=[24, 48, 80], squeeze_excitation=True), seed=11,
+                                        data_seed=1),
     "squeeze_excite_2d": dict(patch=(32, 32), batch=2, in_channels=1, tasks=TASKS_SIGMOID_SHEET, autoconfigure=False,
                               model_config=_manual(squeeze_excitation=True), seed=11, data_seed=5),
 }

