@@ -103,7 +103,7 @@ __device__ inline void se_gather_line(const float* __restrict__ part, int n, int
       float s[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) s[p] = 0.f;
-#pragma unroll 4
+#pragma unroll 8
       for (int t = 0; t < nterms; ++t) {
         const int k = t / XT, x = keep_x ? line : t - k * XT;
         const float* q = part + ((size_t)(n * chunks + k) * NP) * plane + (size_t)x * C + c;
@@ -121,7 +121,7 @@ __device__ inline void se_gather_line(const float* __restrict__ part, int n, int
 #pragma unroll
   for (int p = 0; p < NP; ++p) s[p] = 0.f;
   if (kl < KL) {
-#pragma unroll 4
+#pragma unroll 8
     for (int t = kl; t < nterms; t += KL) {
       const int k = t / XT, x = keep_x ? line : t - k * XT;
       const float* q = part + ((size_t)(n * chunks + k) * NP) * plane + (size_t)x * C + cl;
@@ -252,7 +252,18 @@ __global__ __launch_bounds__(256) void se_m12_kernel(const float* __restrict__ l
   if (i >= N * C) return;
   const int n = i / C, c = i - n * C;
   double a = 0.0, b = 0.0;
-  for (int l = 0; l < L; ++l) {
+  int l = 0;
+  for (; l + 8 <= L; l += 8) {          // 16 loads in flight, added in line order
+    float va[8], vb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      va[u] = line_m[(((size_t)n * L + l + u) * 2 + 0) * C + c];
+      vb[u] = line_m[(((size_t)n * L + l + u) * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += (double)va[u], b += (double)vb[u];
+  }
+  for (; l < L; ++l) {
     a += (double)line_m[(((size_t)n * L + l) * 2 + 0) * C + c];
     b += (double)line_m[(((size_t)n * L + l) * 2 + 1) * C + c];
   }
