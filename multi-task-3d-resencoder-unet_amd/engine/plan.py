@@ -186,7 +186,15 @@ class Plan:
         v = list(v)
         return [1] + v if self.two_d else v
 
+    def _check_extent(self, numel, name):
+        # kernels index elements (and some of them bytes) with 32 bits; the largest size exercised on hardware is 2^31 bytes
+        # per tensor (scripts/big_patch_check.py: 256^3, batch 2, 32 channels, bf16) -- beyond that refuse instead of risking a fault
+        if numel * self.dtype.itemsize > (1 << 31):
+            raise UnsupportedConfig(f"activation tensor {name} would have {numel} elements ({numel * self.dtype.itemsize} bytes > 2^31): "
+                                    "lower the batch or patch size")
+
     def _new(self, dims, c, name, ld=None, needs_grad=True):
+        self._check_extent(self.B * dims[0] * dims[1] * dims[2] * (ld or c), name)
         t = torch.empty((self.B, *dims, ld or c), dtype=self.dtype, device=self.device)
         self.bytes_alloc += t.numel() * t.element_size()
         return AT(Act(t, 0, c), name, needs_grad=needs_grad)
@@ -203,6 +211,7 @@ class Plan:
                   and os.environ.get("RX_PLANAR_CAT", "1") != "0")
         if not planar:
             return self._new(dims, 2 * c, name, ld=2 * c)
+        self._check_extent(2 * self.B * vox * 32, name)
         root = torch.empty((2, self.B, *dims, 32), dtype=self.dtype, device=self.device)
         self.bytes_alloc += root.numel() * root.element_size()
         return AT(Act.planar(root), name)

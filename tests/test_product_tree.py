@@ -168,3 +168,12 @@ def test_reference_task_files_behave_as_upstream():
         assert len(plan.fwd) > 50 and len(plan.bwd) > 50 and set(plan.outputs) == set(m.tasks)
         built += 1
     assert built >= 2          # dumb.yaml (128^3, two heads, SE) and ink.yaml (14 x 256 x 256, SE)
+
+
+def test_oversized_activation_is_refused_before_any_launch():
+    """kernels index with 32 bits in places: the plan refuses a tensor beyond the largest extent exercised on hardware (2^30
+    elements: 256^3 x 32 channels x batch 2, scripts/big_patch_check.py) instead of risking a device fault"""
+    mgr = oracle.make_mgr((320, 320, 320), {"a": {"channels": 1}}, 1, 2, True, {})
+    with pytest.raises(UnsupportedConfig):
+        Plan(NetworkFromConfig(mgr).to("meta"), (2, 1, 320, 320, 320), torch.bfloat16, "meta", True)
+    Plan(NetworkFromConfig(mgr).to("meta"), (1, 1, 256, 256, 256), torch.bfloat16, "meta", False)      # fine
