@@ -1,6 +1,6 @@
-"""GPU-side half of the seed curation for tests/test_network_gpu.py::test_fp32_live_oracle_32cube_two_steps: for data seeds
+"""TEST INFRASTRUCTURE ONLY.  GPU-side half of the seed curation for tests/test_network_gpu.py::test_fp32_live_oracle_32cube_two_steps: for data seeds
 that already have LeakyReLU mask margin on the CPU (oracle fp32 vs fp64 < 2e-5, /oracle/scan_seeds.py procedure), print
-the engine's worst fp32 parameter-gradient distance from the fp64 oracle.  Usage: python scripts/seed_margin_gpu.py cube32|widened 99 103 ..."""
+the engine's worst fp32 parameter-gradient distance from the fp64 oracle.  Usage: python oracle/seed_margin_gpu.py cube32|widened 99 103 ..."""
 import os
 import sys
 

@@ -1,10 +1,13 @@
 """InstanceNorm nets are per-sample: the gradient of a batch is the sum of the gradients of its samples run alone."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT]
 import torch
 import mt3d_amd  # noqa
-import resenc_oracle as oracle
+def _mgr(patch, tasks, cin, batch, autoconfigure, model_config):      # what NetworkFromConfig reads from a ConfigManager
+    from types import SimpleNamespace
+    return SimpleNamespace(tasks=tasks, train_patch_size=tuple(patch), train_batch_size=batch, in_channels=cin, vram_max=16.0,
+                           autoconfigure=autoconfigure, model_config=dict(model_config), verbose=False)
 from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
 patch = {"ink": (14, 256, 256), "c64": (64, 64, 64), "c128": (128, 128, 128)}[sys.argv[1]]
 B = int(sys.argv[2])
@@ -13,7 +16,7 @@ order = sys.argv[3].split(",")
 se = "nose" not in sys.argv
 bias = "nobias" not in sys.argv
 tasks = {"ink": {"channels": 1, "activation": "none"}}
-mgr = oracle.make_mgr(patch, tasks, 1, B, True, {"conv_bias": bias, "squeeze_excitation": se})
+mgr = _mgr(patch, tasks, 1, B, True, {"conv_bias": bias, "squeeze_excitation": se})
 torch.manual_seed(0)
 net = NetworkFromConfig(mgr).cuda()
 gen = torch.Generator(device="cuda").manual_seed(7)

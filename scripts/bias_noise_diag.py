@@ -1,15 +1,18 @@
 """conv biases under InstanceNorm have an analytically zero gradient: how large is what the engine delivers (bf16 vs fp32 compute)?"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT]
 import torch
 import mt3d_amd  # noqa
-import resenc_oracle as oracle
+def _mgr(patch, tasks, cin, batch, autoconfigure, model_config):      # what NetworkFromConfig reads from a ConfigManager
+    from types import SimpleNamespace
+    return SimpleNamespace(tasks=tasks, train_patch_size=tuple(patch), train_batch_size=batch, in_channels=cin, vram_max=16.0,
+                           autoconfigure=autoconfigure, model_config=dict(model_config), verbose=False)
 from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
 patch = (14, 256, 256) if (len(sys.argv) < 2 or sys.argv[1] == "ink") else (64, 64, 64)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 tasks = {"ink": {"channels": 1, "activation": "none"}}
-mgr = oracle.make_mgr(patch, tasks, 1, B, True, {"conv_bias": True, "squeeze_excitation": len(sys.argv) < 4})
+mgr = _mgr(patch, tasks, 1, B, True, {"conv_bias": True, "squeeze_excitation": len(sys.argv) < 4})
 torch.manual_seed(0)
 net = NetworkFromConfig(mgr).cuda()
 gen = torch.Generator(device="cuda").manual_seed(7)

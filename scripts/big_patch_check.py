@@ -2,17 +2,20 @@
 index with 32 bits?  determinism over two steps, finite gradients, sample independence (batch swap), one SGD step reduces the loss."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT]
 import torch
 import mt3d_amd  # noqa
-import resenc_oracle as oracle
+def _mgr(patch, tasks, cin, batch, autoconfigure, model_config):      # what NetworkFromConfig reads from a ConfigManager
+    from types import SimpleNamespace
+    return SimpleNamespace(tasks=tasks, train_patch_size=tuple(patch), train_batch_size=batch, in_channels=cin, vram_max=16.0,
+                           autoconfigure=autoconfigure, model_config=dict(model_config), verbose=False)
 from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
 from mt3d_amd.training.losses.losses import BCEDiceLoss
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 patch = (P, P, P)
 tasks = {"sheet": {"channels": 1, "activation": "none", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
-mgr = oracle.make_mgr(patch, tasks, 1, B, True, {})
+mgr = _mgr(patch, tasks, 1, B, True, {})
 torch.manual_seed(0)
 net = NetworkFromConfig(mgr).cuda()
 net.compute_dtype = torch.bfloat16

@@ -8,18 +8,18 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+sys.path[:0] = [ROOT]
 import torch  # noqa: E402
 
 
 def work(tag, with_sync, passes=8, alt=False):
     import mt3d_amd  # noqa: F401
-    import resenc_oracle as oracle
+    from types import SimpleNamespace
     from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
     from mt3d_amd.engine.ddp import GradSync
     from mt3d_amd.training.losses.losses import BCEDiceLoss
     tasks = {"sheet": {"channels": 1, "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
-    mgr = oracle.make_mgr((128, 128, 128), tasks, 1, 2, True, {})
+    mgr = SimpleNamespace(tasks=tasks, train_patch_size=(128, 128, 128), train_batch_size=2, in_channels=1, vram_max=16.0, autoconfigure=True, model_config={}, verbose=False)
     torch.manual_seed(3)
     net = NetworkFromConfig(mgr).cuda().train()
     gen = torch.Generator().manual_seed(99)

@@ -168,7 +168,7 @@ def test_widened_configs_six_inputs_twelve_class_head(NetworkFromConfig):
         assert (pr[n].grad is None) == (pn[n].grad is None), n
         if pr[n].grad is not None and pr[n].grad.norm() > 1e-6:
             # (data seed 1 has mask margin for this net on the CPU -- oracle fp32 vs fp64 2.5e-6 -- and on the engine, 1.8e-6
-            # against the fp64 oracle: scripts/seed_margin_gpu.py widened; seed 5 flips one mask in the engine's summation order)
+            # against the fp64 oracle: oracle/seed_margin_gpu.py widened; seed 5 flips one mask in the engine's summation order)
             assert rel_l2(pn[n].grad.cpu(), pr[n].grad) < 1e-3, (n, rel_l2(pn[n].grad.cpu(), pr[n].grad))
     ref.eval(); net.eval()
     x, _ = oracle.synthetic_batch(2, 6, (16, 16, 16), tasks, 1)
