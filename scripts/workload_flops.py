@@ -1,7 +1,7 @@
 """algorithmic FLOPs of a bench workload from its (meta-device) plan: 2*V_out*Co*Ci*taps per conv, x3 for a train step"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT]
 import torch, bench
 import mt3d_amd  # noqa
 from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
