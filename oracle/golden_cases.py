@@ -111,6 +111,19 @@ CASES = {
                          full_grads=("stages.0.blocks.0.conv1.conv.weight", "stages.1.blocks.1.conv2.conv.weight",
                                      "seg.stages.1.blocks.0.conv1.conv.weight", "seg.transpconvs.0.weight",
                                      "seg.stages.1.blocks.0.skip.0.conv.weight")),
+    # the round-2 widenings composed: 2-D patch, no stem, feature counts off the K tile, conv_bias, channel dropout, BottleneckD
+    # encoder with its default C/4 bottlenecks (6, 12, 20 channels), ResidualBlock decoder, 3-class softmax head, 2 input channels
+    "combo_2d": dict(patch=(32, 32), batch=2, in_channels=2,
+                     tasks={"seg": {"channels": 3, "activation": "softmax", "weight": 1, "loss_fn": "BCEDiceLoss",
+                                    "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}},
+                     autoconfigure=False,
+                     model_config=_manual(do_stem=False, features_per_stage=[24, 48, 80], conv_bias=True,
+                                          dropout_op_kwargs={"p": 0.2}, basic_encoder_block="BottleneckBlockD",
+                                          bottleneck_block="BottleneckBlockD", basic_decoder_block="ResidualBlock"),
+                     seed=11, data_seed=1, train=True,
+                     full_grads=("stages.0.blocks.0.conv1.conv.weight", "stages.0.blocks.0.skip.0.conv.weight",
+                                 "stages.1.blocks.1.conv2.conv.weight", "seg.transpconvs.1.weight",
+                                 "seg.stages.1.blocks.0.conv1.conv.weight")),
 }
 
 # Cases WITHOUT a reference fixture -- PARITY UNPINNED: SqueezeExcite / DropPath live in the un-vendored

@@ -50,7 +50,9 @@ def forced_dropout(masks):
 
     def draw(self, d):
         i = next(j for j, e in enumerate(self._drops) if e is d)
-        d["keep"].copy_(torch.as_tensor(masks[i]))
+        mk = torch.as_tensor(masks[i])
+        d["keep"].fill_(1.0)                               # (padding channels of a padded buffer are zero whatever they keep)
+        d["keep"][:, :mk.shape[1]].copy_(mk)
     plan_mod.Plan._draw_dropout = draw
     try:
         yield
