@@ -196,7 +196,7 @@ int rx_stem_conv_bwd_weight(rx_dtype dt, const float* x_ncdhw, int n, int cin, i
                             const rx_act* dy, float* dw, const int32_t kernel[3], void* ws, size_t ws_bytes,
                             void* stream);
 
-/* ---- task head: Conv3d 1x1x1 with bias to K <= 16 channels, NCDHW fp32 logits, optional
+/* ---- task head: Conv3d 1x1x1 with bias to K <= 64 channels, NCDHW fp32 logits, optional
  *      eval-mode activation (decoder.py:131,151-152; build_network_from_config.py:320-323) ---- */
 int rx_head_fwd(rx_dtype dt, const rx_act* x, const float* w, const float* b, int k, float* out_ncdhw,
                 int act, void* stream);

@@ -1019,8 +1019,9 @@ extern "C" int rx_avgpool_bwd(rx_dtype dt, const rx_act* dy, const rx_act* dx, c
   return RX_OK;
 }
 
-// ---- task head: 1x1x1 conv with bias to K <= 16 channels (accumulator arrays sized 8 or 16: K <= 8 keeps the lean kernel) ---
-#define RX_HEAD_MAXK 16
+// ---- task head: 1x1x1 conv with bias to K <= 64 channels (forward: accumulator arrays sized 8 / 16 / 32 / 64, K <= 8 keeps the
+// lean kernel; backward: weight / bias gradients in chunks of <= 16 output channels, the data gradient over all K in chunk 0) ---
+#define RX_HEAD_MAXK 64
 template <typename T, int MAXK>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, int ldx, long sx, const float* __restrict__ w,
                                                        const float* __restrict__ b, int K, float* __restrict__ out, int V, int C, int act) {
@@ -1076,31 +1077,41 @@ extern "C" int rx_head_fwd(rx_dtype dt, const rx_act* x, const float* w, const f
   if (k < 1 || k > RX_HEAD_MAXK) RX_FAIL(RX_EUNSUPPORTED, "rx_head_fwd: 1 <= K <= %d (got %d)", RX_HEAD_MAXK, k);
   const long V = rx_act_voxels(x);
   hipStream_t st = (hipStream_t)stream;
+#define RX_LAUNCH_HEAD_FWD(MK)                                                                                                        \
+  hipLaunchKernelGGL((head_fwd_kernel<T, MK>), dim3(G, x->n), dim3(256), (size_t)k * x->c * sizeof(float), st, (const T*)x->ptr, x->ld,  \
+                     V * x->ld, w, b, k, out_ncdhw, (int)V, x->c, act)
   RX_DISPATCH_DTYPE(dt, T, {
     int G = (int)((V + 255) / 256 > 4096 ? 4096 : (V + 255) / 256);
     if (k <= 8)
-      hipLaunchKernelGGL((head_fwd_kernel<T, 8>), dim3(G, x->n), dim3(256), (size_t)k * x->c * sizeof(float), st, (const T*)x->ptr, x->ld,
-                         V * x->ld, w, b, k, out_ncdhw, (int)V, x->c, act);
+      RX_LAUNCH_HEAD_FWD(8);
+    else if (k <= 16)
+      RX_LAUNCH_HEAD_FWD(16);
+    else if (k <= 32)
+      RX_LAUNCH_HEAD_FWD(32);
     else
-      hipLaunchKernelGGL((head_fwd_kernel<T, 16>), dim3(G, x->n), dim3(256), (size_t)k * x->c * sizeof(float), st, (const T*)x->ptr, x->ld,
-                         V * x->ld, w, b, k, out_ncdhw, (int)V, x->c, act);
+      RX_LAUNCH_HEAD_FWD(64);
+
   });
+#undef RX_LAUNCH_HEAD_FWD
   RX_CHECK_LAUNCH("rx_head_fwd");
   return RX_OK;
 }
 
 // backward: dx[v][c] = sum_k dout[k][v] w[k][c]; dw[k][c] = sum_v dout[k][v] x[v][c]; db[k] = sum_v dout[k][v]
+// One launch handles the output channels [k0, k0 + K) of a head with Kt of them: dw / db of that range; dx (over ALL Kt channels,
+// a run-time loop: it needs no per-channel registers) when dx != nullptr -- the caller passes it with the first chunk only.
 template <typename T, int MAXK>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ x, int ldx, long sx,
-                                                       const float* __restrict__ w, int K, T* __restrict__ dx, int lddx, long sdx, int V,
-                                                       int C, int chunk_vox, float* __restrict__ partial /*[N][nch][K+1][C]*/) {
+                                                       const float* __restrict__ w, int K, int k0, int Kt, T* __restrict__ dx, int lddx,
+                                                       long sdx, int V, int C, int chunk_vox,
+                                                       float* __restrict__ partial /*[N][nch][K+1][C]*/) {
   constexpr int P = Elem<T>::PER16;
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // sw[K][C] then red[(K+1)][VP][C]
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // sw[Kt][C] then red[(K+1)][VP][C]
   float* sw = sm;
   const int CV = C / P;
   const int VP = 256 / CV > 0 ? 256 / CV : 1;
-  float* red = sm + K * C;
-  for (int i = threadIdx.x; i < K * C; i += 256) sw[i] = w[i];
+  float* red = sm + Kt * C;
+  for (int i = threadIdx.x; i < Kt * C; i += 256) sw[i] = w[i];
   __syncthreads();
   const int tid = threadIdx.x, n = blockIdx.y, chunk = blockIdx.x;
   const int vl = tid / CV, cv = tid - vl * CV;
@@ -1122,14 +1133,21 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 #pragma unroll
       for (int k = 0; k < MAXK; ++k)
         if (k < K) {
-          float gk = dout[((size_t)n * K + k) * V + v];
+          float gk = dout[((size_t)n * Kt + k0 + k) * V + v];
           ab[k] += gk;
 #pragma unroll
           for (int j = 0; j < P; ++j) {
             aw[k][j] += gk * Elem<T>::to_f(xv.v[j]);
-            d[j] += gk * sw[k * C + cv * P + j];
+            if (Kt == K) d[j] += gk * sw[k * C + cv * P + j];
           }
         }
+      if (dx && Kt != K) {      // more channels than this launch's chunk: the data gradient sums over all of them (k ascending)
+        for (int k = 0; k < Kt; ++k) {
+          const float gk = dout[((size_t)n * Kt + k) * V + v];
+#pragma unroll
+          for (int j = 0; j < P; ++j) d[j] += gk * sw[k * C + cv * P + j];
+        }
+      }
       if (dx) {
         Vec16<T> o;
 #pragma unroll
@@ -1173,33 +1191,38 @@ extern "C" int rx_head_bwd(rx_dtype dt, const float* dout_ncdhw, const rx_act* x
     if (!same_geom(x, dx)) RX_FAIL(RX_EINVAL, "rx_head_bwd: dx geometry mismatch");
   }
   if (!dout_ncdhw || !w || !dw || !db || !ws) RX_FAIL(RX_EINVAL, "rx_head_bwd: null pointer");
-  if (k < 1 || k > RX_HEAD_MAXK || k > x->c) RX_FAIL(RX_EUNSUPPORTED, "rx_head_bwd: 1 <= K <= %d", RX_HEAD_MAXK);
+  if (k < 1 || k > RX_HEAD_MAXK || (k <= 16 && k > x->c) || x->c < 16) RX_FAIL(RX_EUNSUPPORTED, "rx_head_bwd: 1 <= K <= %d", RX_HEAD_MAXK);
   const long V = rx_act_voxels(x);
   const int N = x->n, C = x->c;
   hipStream_t st = (hipStream_t)stream;
   RX_DISPATCH_DTYPE(dt, T, {
     constexpr int P = Elem<T>::PER16;
     ReducePlan p = rx_reduce_plan(V, C, P);
-    size_t need = (size_t)N * p.nchunks * (k + 1) * C * sizeof(float) + (size_t)(k + 1) * C * sizeof(float) + 256;
+    const int kc_max = k <= 16 ? k : 16;           // output channels per launch
+    size_t need = (size_t)N * p.nchunks * (kc_max + 1) * C * sizeof(float) + (size_t)(kc_max + 1) * C * sizeof(float) + 256;
     if (ws_bytes < need) RX_FAIL(RX_EWORKSPACE, "rx_head_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
     int CV = C / P, VP = 256 / CV;
     float* partial = (float*)ws;
-    float* fin = partial + (size_t)N * p.nchunks * (k + 1) * C;
-    size_t lds = ((size_t)k * C + (size_t)(k + 1) * VP * C) * sizeof(float);
+    float* fin = partial + (size_t)N * p.nchunks * (kc_max + 1) * C;
+    size_t lds = ((size_t)k * C + (size_t)(kc_max + 1) * VP * C) * sizeof(float);
     if (lds > 160 * 1024) RX_FAIL(RX_EUNSUPPORTED, "rx_head_bwd: K = %d needs %zu bytes of LDS", k, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<T, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<T, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (k <= 8) {
-      hipLaunchKernelGGL((head_bwd_kernel<T, 8>), dim3(p.nchunks, N), dim3(256), lds, st, dout_ncdhw, (const T*)x->ptr, x->ld, V * x->ld, w, k,
-                         dx ? (T*)dx->ptr : (T*)nullptr, dx ? dx->ld : 0, dx ? V * dx->ld : 0L, (int)V, C, p.chunk_vox, partial);
-    } else {
-      hipLaunchKernelGGL((head_bwd_kernel<T, 16>), dim3(p.nchunks, N), dim3(256), lds, st, dout_ncdhw, (const T*)x->ptr, x->ld, V * x->ld, w, k,
-                         dx ? (T*)dx->ptr : (T*)nullptr, dx ? dx->ld : 0, dx ? V * dx->ld : 0L, (int)V, C, p.chunk_vox, partial);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<T, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<T, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int k0 = 0; k0 < k; k0 += 16) {
+      const int kc = k - k0 < 16 ? k - k0 : 16;
+      T* dxp = (dx && k0 == 0) ? (T*)dx->ptr : (T*)nullptr;
+      if (kc <= 8) {
+        hipLaunchKernelGGL((head_bwd_kernel<T, 8>), dim3(p.nchunks, N), dim3(256), lds, st, dout_ncdhw, (const T*)x->ptr, x->ld, V * x->ld, w, kc,
+                           k0, k, dxp, dx ? dx->ld : 0, dx ? V * dx->ld : 0L, (int)V, C, p.chunk_vox, partial);
+      } else {
+        hipLaunchKernelGGL((head_bwd_kernel<T, 16>), dim3(p.nchunks, N), dim3(256), lds, st, dout_ncdhw, (const T*)x->ptr, x->ld, V * x->ld, w, kc,
+                           k0, k, dxp, dx ? dx->ld : 0, dx ? V * dx->ld : 0L, (int)V, C, p.chunk_vox, partial);
+      }
+      hipLaunchKernelGGL(colreduce_finalize, dim3(((kc + 1) * C + 3) / 4), dim3(256), 0, st, (const float*)partial, N, p.nchunks, kc + 1,
+                         C, (double)V, 0.f, (int)FIN_SUM_OVER_N, fin);
+      (void)hipMemcpyAsync(dw + (size_t)k0 * C, fin, (size_t)kc * C * sizeof(float), hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync(db + k0, fin + (size_t)kc * C, (size_t)kc * sizeof(float), hipMemcpyDeviceToDevice, st);
     }
-    hipLaunchKernelGGL(colreduce_finalize, dim3(((k + 1) * C + 3) / 4), dim3(256), 0, st, (const float*)partial, N, p.nchunks, k + 1,
-                       C, (double)V, 0.f, (int)FIN_SUM_OVER_N, fin);
-    (void)hipMemcpyAsync(dw, fin, (size_t)k * C * sizeof(float), hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(db, fin + (size_t)k * C, (size_t)k * sizeof(float), hipMemcpyDeviceToDevice, st);
   });
   RX_CHECK_LAUNCH("rx_head_bwd");
   return RX_OK;

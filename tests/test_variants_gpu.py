@@ -154,12 +154,13 @@ def test_droppath_training_and_eval(NetworkFromConfig):
         assert rel_l2(e_n[k].cpu(), e_r[k]) < 2e-4
 
 
-def test_widened_configs_six_inputs_twelve_class_head(NetworkFromConfig):
-    """round 2 widening: in_channels up to 8 (the stem's VALU kernels above 4) and task heads up to 16
-    channels (softmax over 12 classes here), against the oracle in fp32 mode.  The 12-channel BCE-Dice loss takes torch's
-    path (the HIP loss kernels cover C <= 8)."""
-    tasks = {"seg": {"channels": 12, "activation": "softmax", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
-    ref, net, o_r, o_n, l_r, l_n = _run(NetworkFromConfig, (16, 16, 16), 6, tasks, manual(), batch=2, seed=11, data_seed=1)
+@pytest.mark.parametrize("classes,data_seed", [(12, 1), (40, 1)])
+def test_widened_configs_six_inputs_twelve_class_head(NetworkFromConfig, classes, data_seed):
+    """round 2 widening: in_channels up to 8 (the stem's VALU kernels above 4) and task heads up to 64
+    channels (softmax over 12 / 40 classes here; above 16 the head's weight gradient runs in chunks of 16 output channels),
+    against the oracle in fp32 mode.  The multi-channel BCE-Dice loss takes torch's path (the HIP loss kernels cover C <= 8)."""
+    tasks = {"seg": {"channels": classes, "activation": "softmax", "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
+    ref, net, o_r, o_n, l_r, l_n = _run(NetworkFromConfig, (16, 16, 16), 6, tasks, manual(), batch=2, seed=11, data_seed=data_seed)
     assert rel_l2(o_n["seg"].cpu(), o_r["seg"].detach()) < 2e-4
     assert torch.equal(o_n["seg"].cpu().argmax(1), o_r["seg"].argmax(1))
     assert abs(l_r.item() - l_n.item()) < 1e-4
