@@ -1,0 +1,112 @@
+"""GPU (-m gpu): randomized differential test over the reference's config surface -- 36 small networks drawn from a fixed
+generator (encoder block type, decoder block type, feature counts on and off the 32-channel tile, blocks per stage, per-axis
+kernels / strides, conv_bias, SqueezeExcite, do_stem, 2-D / 3-D, 1-8 input channels, 1-20 output classes with and without
+softmax, batch 1-3, ReLU / LeakyReLU, decoder convs per stage) against the CPU oracle in fp32 mode.  Logits carry the 2e-4 bar;
+the data seeds are not curated for LeakyReLU mask margin, so gradients are checked by magnitude and direction (a mask flip moves a
+tensor by 1e-3..2e-2, a wiring bug by O(1)): cosine > 0.999 and norm ratio within 2 %, for every parameter that has a gradient --
+and exactly the same set of parameters must have one."""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import resenc_oracle as oracle
+from helpers import rel_l2
+
+
+def draw(rng):
+    two_d = rng.random() < 0.25
+    nd = 2 if two_d else 3
+    n_st = rng.choice([2, 3, 3, 4])
+    base = rng.choice([16, 24, 32, 32, 40, 48])
+    feats = [min(base * 2 ** i, rng.choice([96, 128, 160])) for i in range(n_st)]
+    enc = rng.choice(["BasicBlockD", "BasicBlockD", "BottleneckBlockD", "ResidualBlock"])      # "ResidualBlock": the plain-conv quirk
+    dec = rng.choice(["ConvBlock", "ConvBlock", "ResidualBlock"])
+    aniso = (not two_d) and rng.random() < 0.3
+    kernels, strides = [], []
+    for s in range(n_st):
+        k = [rng.choice([1, 3]) if aniso and s == 0 else 3 for _ in range(nd)]
+        st = [1] * nd if s == 0 else [rng.choice([1, 2]) if aniso else 2 for _ in range(nd)]
+        if s > 0 and all(v == 1 for v in st):
+            st[-1] = 2
+        kernels.append(k), strides.append(st)
+    total = [1] * nd
+    for st in strides:
+        total = [a * b for a, b in zip(total, st)]
+    patch = tuple(t * rng.choice([2, 3] if t >= 8 else [2, 4]) for t in total)
+    if two_d:
+        patch = tuple(max(p, 16) // t * t if False else p for p, t in zip(patch, total))
+    mc = {"basic_encoder_block": enc, "basic_decoder_block": dec,
+          "bottleneck_block": "BottleneckBlockD" if enc == "BottleneckBlockD" else "BasicBlockD",
+          "features_per_stage": feats, "num_stages": n_st, "n_blocks_per_stage": [rng.choice([1, 2]) for _ in range(n_st)],
+          "kernel_sizes": kernels, "n_conv_per_stage_decoder": [rng.choice([1, 2]) for _ in range(n_st - 1)], "strides": strides,
+          "conv_bias": rng.random() < 0.5, "nonlin": rng.choice(["nn.LeakyReLU", "nn.LeakyReLU", "nn.ReLU"])}
+    if enc != "ResidualBlock" and rng.random() < 0.35:
+        mc["squeeze_excitation"] = True
+    if rng.random() < 0.25:
+        mc["do_stem"] = False
+    classes = rng.choice([1, 1, 2, 3, 5, 12, 20])
+    act = "softmax" if classes > 1 and rng.random() < 0.6 else ("sigmoid" if rng.random() < 0.5 else "none")
+    tasks = {"t": {"channels": classes, "activation": act, "weight": 1, "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
+    if rng.random() < 0.3:
+        tasks["n"] = {"channels": 3, "activation": "none", "weight": 0.5, "loss_fn": "MaskedCosineLoss"}
+    return dict(patch=patch, cin=rng.choice([1, 1, 2, 3, 6, 8]), batch=rng.choice([1, 2, 3]), mc=mc, tasks=tasks)
+
+
+def configs(n=36, seed=20260):
+    rng = random.Random(seed)
+    return [draw(rng) for _ in range(n)]
+
+
+@pytest.fixture(scope="module")
+def NetworkFromConfig():
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.builders.build_network_from_config import NetworkFromConfig as N
+    return N
+
+
+@pytest.mark.parametrize("i", range(36))
+def test_random_config_matches_the_oracle(NetworkFromConfig, i):
+    from mt3d_amd.engine.plan import UnsupportedConfig
+    c = configs()[i]
+    mgr = oracle.make_mgr(c["patch"], c["tasks"], c["cin"], c["batch"], False, c["mc"])
+    torch.manual_seed(100 + i)
+    try:
+        ref = oracle.NetworkFromConfig(mgr)
+    except (ValueError, AssertionError, RuntimeError, IndexError) as e:       # a topology the reference itself cannot build
+        pytest.skip(f"oracle refuses: {type(e).__name__}: {e}")
+    torch.manual_seed(100 + i)
+    net = NetworkFromConfig(mgr).cuda()
+    net.compute_dtype = torch.float32
+    assert list(ref.state_dict().keys()) == list(net.state_dict().keys())
+    x, t = oracle.synthetic_batch(c["batch"], c["cin"], c["patch"], c["tasks"], 7 + i)
+    try:
+        o_r = ref(x)
+    except (RuntimeError, ValueError) as e:                                   # e.g. concat size mismatch of an odd topology
+        pytest.skip(f"oracle forward fails: {e}")
+    try:
+        o_n = net(x.cuda())
+    except UnsupportedConfig as e:
+        pytest.skip(f"loudly rejected: {e}")
+    for k in o_r:
+        assert rel_l2(o_n[k].cpu(), o_r[k].detach()) < 2e-4, (c, k)
+    l_r = oracle.train_loss(o_r, t, c["tasks"])
+    l_n = oracle.train_loss(o_n, {k: v.cuda() for k, v in t.items()}, c["tasks"])
+    assert abs(l_r.item() - l_n.item()) < 1e-4 * max(1.0, abs(l_r.item()))
+    l_r.backward()
+    l_n.backward()
+    pr, pn = dict(ref.named_parameters()), dict(net.named_parameters())
+    for n in pr:
+        assert (pr[n].grad is None) == (pn[n].grad is None), (c, n)
+        if pr[n].grad is None or pr[n].grad.norm() < 1e-6:
+            continue
+        a, b = pn[n].grad.double().flatten().cpu(), pr[n].grad.double().flatten()
+        cos = (a @ b / (a.norm() * b.norm())).item()
+        assert cos > 0.999 and abs(a.norm().item() / b.norm().item() - 1) < 2e-2, (c, n, cos, a.norm().item() / b.norm().item())
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        e_r, e_n = ref(x), net(x.cuda())
+    for k in e_r:
+        assert rel_l2(e_n[k].cpu(), e_r[k]) < 2e-4, (c, k)
