@@ -304,7 +304,9 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
 int rx_stem_fwd_mfma_try(rx_dtype dt, const float* x, int n, int cin, int z, int y, int xx, const float* w, const float* bias,
                          const rx_act* out, const int32_t kernel[3], hipStream_t st) {
   const int K = cin * kernel[0] * kernel[1] * kernel[2];
-  if (dt == RX_F32 || out->c != 32 || out->ld % 4 || ((uintptr_t)out->ptr & 7) || K > 112) return 0;
+  // (the kernel stages at most 4 input channels: with 5-8 of them a small kernel -- K = Cin * taps <= 112 -- used to be accepted
+  // here and computed garbage; found by tests/test_fuzz_gpu.py)
+  if (dt == RX_F32 || out->c != 32 || out->ld % 4 || ((uintptr_t)out->ptr & 7) || K > 112 || cin > 4) return 0;
   const int NT = n * ((z + 3) / 4) * ((y + 3) / 4) * ((xx + 15) / 16);
   static int maxb = -1;
   if (maxb < 0) {

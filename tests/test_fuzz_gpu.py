@@ -110,3 +110,39 @@ def test_random_config_matches_the_oracle(NetworkFromConfig, i):
         e_r, e_n = ref(x), net(x.cuda())
     for k in e_r:
         assert rel_l2(e_n[k].cpu(), e_r[k]) < 2e-4, (c, k)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("i", range(0, 36, 2))
+def test_random_config_low_precision_modes(NetworkFromConfig, i, dtype):
+    """the same draw in the 16-bit throughput modes (other kernel instantiations: MFMA K tile 32, 16-byte vectors of 8): logits
+    within the drift the reference's own autocast shows (4e-2 bf16 / 8e-3 fp16 of the fp32 oracle, x1.5 for the tiny extents
+    drawn here), the loss within 3e-2, finite gradients for exactly the parameters the oracle gives one, two steps bit-identical."""
+    c = configs()[i]
+    mgr = oracle.make_mgr(c["patch"], c["tasks"], c["cin"], c["batch"], False, c["mc"])
+    torch.manual_seed(100 + i)
+    ref = oracle.NetworkFromConfig(mgr)
+    torch.manual_seed(100 + i)
+    net = NetworkFromConfig(mgr).cuda()
+    net.compute_dtype = dtype
+    x, t = oracle.synthetic_batch(c["batch"], c["cin"], c["patch"], c["tasks"], 7 + i)
+    o_r = ref(x)
+    l_r = oracle.train_loss(o_r, t, c["tasks"])
+    l_r.backward()
+    runs = []
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        o_n = net(x.cuda())
+        l_n = oracle.train_loss(o_n, {k: v.cuda() for k, v in t.items()}, c["tasks"])
+        l_n.backward()
+        runs.append(({k: v.detach().clone() for k, v in o_n.items()}, {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+    for k in o_r:
+        assert torch.equal(runs[0][0][k], runs[1][0][k])
+        tol = (6e-2 if dtype == torch.bfloat16 else 1.2e-2)
+        assert rel_l2(runs[0][0][k].cpu(), o_r[k].detach()) < tol, (c, k, rel_l2(runs[0][0][k].cpu(), o_r[k].detach()))
+    assert abs(l_r.item() - l_n.item()) < 3e-2 * max(1.0, abs(l_r.item()))
+    have = {n for n, p in ref.named_parameters() if p.grad is not None}
+    assert set(runs[0][1]) == have
+    for n, g in runs[0][1].items():
+        assert torch.isfinite(g).all(), n
+        assert torch.equal(g, runs[1][1][n]), n
