@@ -199,14 +199,14 @@ class Plan:
         self.bytes_alloc += t.numel() * t.element_size()
         return AT(Act(t, 0, c), name, needs_grad=needs_grad)
 
-    def _new_cat(self, dims, c, name):
+    def _new_cat(self, dims, c, name, allow_planar=True):
         """concat buffer (upsampled | skip) of a decoder stage.  Interleaved (2c channels per voxel, the halves are channel
         slices) in general; PLANAR -- two dense c-channel tensors, rx_act.cs -- for the 32-channel full-resolution level, where
         a 64-byte slice of a 128-byte voxel costs every kernel that streams a half 1.5-2x (scripts/probes/strided_probe.py)
         and the three conv kernels that read / write the whole concat can address its planes separately."""
         vox = dims[0] * dims[1] * dims[2]
         min_vox = int(os.environ.get("RX_PLANAR_MIN_VOXELS", str(64 ** 3)))
-        planar = (c == 32 and self.dtype != torch.float32 and not self.two_d and dims[2] % 16 == 0 and vox >= min_vox
+        planar = (allow_planar and c == 32 and self.dtype != torch.float32 and not self.two_d and dims[2] % 16 == 0 and vox >= min_vox
                   and self.B * (dims[0] // 4) * (dims[1] // 4) * (dims[2] // 16) >= 256
                   and os.environ.get("RX_PLANAR_CAT", "1") != "0")
         if not planar:
@@ -462,7 +462,13 @@ class Plan:
             row = []
             for j in range(n_st - 1):
                 es = n_st - 2 - j
-                cat = self._new_cat(dims[es], featsp[es], f"cat{d}.{j}")
+                # the planar layout is addressed as a whole only by the 3x3x3 stride-1 halo kernels: the stage that reads the concat
+                # must be a plain conv stack starting with such a conv (a ResidualBlock stage also reads it through a 1x1x1 projection;
+                # found by tests/test_fuzz_gpu.py)
+                st_mod = net.task_decoders[tasks[d]].stages[j]
+                first = None if hasattr(st_mod, "blocks") else st_mod.convs[0]
+                halo_ok = first is not None and list(self._k3(first.spec()["kernel"])) == [3, 3, 3]
+                cat = self._new_cat(dims[es], featsp[es], f"cat{d}.{j}", allow_planar=halo_ok)
                 cat.segs = [(0, feats[es], 0), (feats[es], feats[es], featsp[es])]     # (weight range start, length, buffer start)
                 row.append(cat)
             cats.append(row)

@@ -1,4 +1,4 @@
-"""first layer where the 16-bit engine leaves the fp32 engine: python scripts/layer_diff.py <fuzz index> [bf16|fp16]"""
+"""first layer where the 16-bit engine leaves the fp32 engine: python scripts/layer_diff.py <fuzz index> [bf16|fp16] [medium]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
@@ -8,13 +8,14 @@ from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
 from types import SimpleNamespace
 import test_fuzz_gpu as fz
 i = int(sys.argv[1]); dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[sys.argv[2] if len(sys.argv) > 2 else "bf16"]
-c = fz.configs()[i]
+medium = len(sys.argv) > 3 and sys.argv[3] == "medium"          # (RX_FUZZ_SEED selects the draw set, as in the test)
+c = (fz.medium_configs() if medium else fz.configs())[i]
 print(c)
 mgr = SimpleNamespace(tasks=c["tasks"], train_patch_size=tuple(c["patch"]), train_batch_size=c["batch"], in_channels=c["cin"], vram_max=16.0,
                       autoconfigure=False, model_config=dict(c["mc"]), verbose=False)
-torch.manual_seed(100 + i)
+torch.manual_seed((300 if medium else 100) + i)
 net = NetworkFromConfig(mgr).cuda()
-g = torch.Generator().manual_seed(7 + i)
+g = torch.Generator().manual_seed((40 if medium else 7) + i)
 x = torch.rand((c["batch"], c["cin"], *c["patch"]), generator=g).cuda()
 acts = {}
 for d in (torch.float32, dt):
