@@ -252,3 +252,100 @@ def test_random_medium_config_16bit_paths_agree_with_fp32(NetworkFromConfig, i):
             cos = (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
             # (bf16 flips ~1 % of the LeakyReLU masks per layer: 0.85-0.9 seen on BottleneckD stacks; a wiring bug gives ~0)
             assert cos > (0.8 if dt == torch.bfloat16 else 0.98), (c, dt, n, cos)
+
+
+# ---- channel dropout on random topologies: the same kept planes on both sides ---------------------------------------------------
+@pytest.mark.parametrize("i", range(0, 36, 3))
+def test_random_config_with_channel_dropout(NetworkFromConfig, i):
+    """the draw of test_random_config_matches_the_oracle with `dropout_op_kwargs: {p: 0.3}`: the engine's masks (forced from a
+    CPU generator, one per dropout layer in forward order) are handed to the oracle's nn.Dropout modules in their execution
+    order; fp32 logits 2e-4, gradients by direction / magnitude, eval mode identical to the run without dropout."""
+    from mt3d_amd.engine import plan as plan_mod
+    c = configs()[i]
+    p = 0.3
+    mc = dict(c["mc"], dropout_op_kwargs={"p": p})
+    mgr = oracle.make_mgr(c["patch"], c["tasks"], c["cin"], c["batch"], False, mc)
+    torch.manual_seed(100 + i)
+    ref = oracle.NetworkFromConfig(mgr)
+    torch.manual_seed(100 + i)
+    net = NetworkFromConfig(mgr).cuda()
+    net.compute_dtype = torch.float32
+    x, t = oracle.synthetic_batch(c["batch"], c["cin"], c["patch"], c["tasks"], 7 + i)
+    gen = torch.Generator().manual_seed(900 + i)
+    masks = {}
+
+    def draw_mask(self, d):
+        j = next(k for k, e in enumerate(self._drops) if e is d)
+        if j not in masks:
+            masks[j] = torch.bernoulli(torch.full(tuple(d["keep"].shape), 1 - p), generator=gen)
+        d["keep"].copy_(masks[j])
+    orig = plan_mod.Plan._draw_dropout
+    plan_mod.Plan._draw_dropout = draw_mask
+    try:
+        o_n = net(x.cuda())
+        plan = next(iter(net._plans.values()))
+        # the oracle's dropout modules in execution order; module k multiplies by mask k / (1 - p) on its real channels
+        mods = []
+        hooks = [m.register_forward_pre_hook(lambda mod, inp: mods.append(mod))
+                 for m in ref.modules() if isinstance(m, (torch.nn.Dropout3d, torch.nn.Dropout2d))]
+        with torch.no_grad():
+            ref(x)
+        for h in hooks:
+            h.remove()
+        assert len(mods) == len(plan._drops) == len(masks) > 0
+
+        def forced(mk):
+            def fwd(inp):
+                cr = inp.shape[1]
+                return inp * (mk[:, :cr] / (1 - p)).view(inp.shape[0], cr, *([1] * (inp.dim() - 2))).to(inp.dtype)
+            return fwd
+        for k, m in enumerate(mods):
+            m.forward = forced(masks[k])
+        o_r = ref(x)
+        for k in o_r:
+            assert rel_l2(o_n[k].cpu(), o_r[k].detach()) < 2e-4, (c, k, rel_l2(o_n[k].cpu(), o_r[k].detach()))
+        l_r = oracle.train_loss(o_r, t, c["tasks"])
+        l_n = oracle.train_loss(o_n, {k: v.cuda() for k, v in t.items()}, c["tasks"])
+        l_r.backward()
+        l_n.backward()
+    finally:
+        plan_mod.Plan._draw_dropout = orig
+    pr, pn = dict(ref.named_parameters()), dict(net.named_parameters())
+    for n in pr:
+        assert (pr[n].grad is None) == (pn[n].grad is None), (c, n)
+        if pr[n].grad is None or pr[n].grad.norm() < 1e-6 or n.endswith(".conv.bias"):
+            continue
+        a, b = pn[n].grad.double().flatten().cpu(), pr[n].grad.double().flatten()
+        cos = (a @ b / (a.norm() * b.norm())).item()
+        assert cos > 0.999 and abs(a.norm().item() / b.norm().item() - 1) < 2e-2, (c, n, cos, a.norm().item() / b.norm().item())
+
+
+# ---- launch programs on random launch lists ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("i", [1, 5, 9, 13])
+def test_random_medium_config_program_replay_is_bit_identical(NetworkFromConfig, monkeypatch, i):
+    """recorded launch programs replay exactly what an eager pass issues, whatever the launch list: 5 bf16 training steps of a
+    random medium draw with RX_PROGRAMS=1 and =0 end in identical losses and parameters"""
+    c = medium_configs()[i]
+
+    def run(programs):
+        monkeypatch.setenv("RX_PROGRAMS", "1" if programs else "0")
+        mgr = oracle.make_mgr(c["patch"], c["tasks"], c["cin"], c["batch"], False, c["mc"])
+        torch.manual_seed(300 + i)
+        net = NetworkFromConfig(mgr).cuda()
+        net.compute_dtype = torch.bfloat16
+        opt = torch.optim.SGD(net.parameters(), lr=0.05)
+        losses = []
+        for step in range(5):
+            x, t = oracle.synthetic_batch(c["batch"], c["cin"], c["patch"], c["tasks"], 500 + step)
+            out = net(x.cuda())
+            loss = oracle.train_loss(out, {k: v.cuda() for k, v in t.items()}, c["tasks"])
+            loss.backward()
+            losses.append(loss.item())
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        return losses, {n: p.detach().clone() for n, p in net.named_parameters()}
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert l0 == l1
+    for n in p0:
+        assert torch.equal(p0[n], p1[n]), n
