@@ -349,3 +349,69 @@ def test_random_medium_config_program_replay_is_bit_identical(NetworkFromConfig,
     assert l0 == l1
     for n in p0:
         assert torch.equal(p0[n], p1[n]), n
+
+
+# ---- large irregular shapes: the full-resolution kernel instantiations (planar concat, fused statistics, fused head) ----------
+def large_configs(n=6, seed=4242):
+    seed = int(__import__("os").environ.get("RX_FUZZ_SEED", seed))
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        n_st = rng.choice([4, 5, 5, 6])
+        total = 2 ** (n_st - 1)
+        patch = tuple(total * rng.choice([3, 4, 5, 6, 7, 8]) for _ in range(3))
+        while patch[0] * patch[1] * patch[2] > 2_400_000:
+            patch = tuple(sorted(patch))
+            patch = (patch[0], patch[1], patch[2] - total)
+        mc = {"basic_encoder_block": "BasicBlockD", "basic_decoder_block": rng.choice(["ConvBlock", "ConvBlock", "ResidualBlock"]),
+              "bottleneck_block": "BasicBlockD", "features_per_stage": [min(32 * 2 ** i, 256) for i in range(n_st)], "num_stages": n_st,
+              "n_blocks_per_stage": [1] + [rng.choice([1, 2]) for _ in range(n_st - 1)], "kernel_sizes": [[3, 3, 3]] * n_st,
+              "n_conv_per_stage_decoder": [1] * (n_st - 1), "strides": [[1, 1, 1]] + [[2, 2, 2]] * (n_st - 1),
+              "conv_bias": rng.random() < 0.5, "squeeze_excitation": rng.random() < 0.4}
+        tasks = {"t": {"channels": rng.choice([1, 2, 3]), "activation": "none", "weight": 1, "loss_fn": "BCEDiceLoss",
+                       "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
+        if rng.random() < 0.4:
+            tasks["n"] = {"channels": 3, "activation": "none", "weight": 1, "loss_fn": "MaskedCosineLoss"}
+        out.append(dict(patch=patch, cin=rng.choice([1, 1, 2]), batch=rng.choice([1, 2, 3]), mc=mc, tasks=tasks))
+    return out
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_random_large_config_bf16_agrees_with_fp32_engine(NetworkFromConfig, i):
+    """1-2.4 M voxels per sample with extents that are multiples of the total stride only (e.g. 96 x 112 x 80): the bf16 engine
+    (persistent halo kernels, planar concat, statistics from conv epilogues, fused head, InstanceNorm-backward sums from
+    data-gradient epilogues) against the fp32 engine (generic kernels): logits within the bf16 drift, loss, gradient direction of
+    the heaviest tensors, two bf16 steps bit-identical.  (The fp32 engine is pinned to the oracle at the smaller sizes above.)"""
+    c = large_configs()[i]
+    mgr = oracle.make_mgr(c["patch"], c["tasks"], c["cin"], c["batch"], False, c["mc"])
+    torch.manual_seed(700 + i)
+    net = NetworkFromConfig(mgr).cuda()
+    x, t = oracle.synthetic_batch(c["batch"], c["cin"], c["patch"], c["tasks"], 70 + i)
+    x, t = x.cuda(), {k: v.cuda() for k, v in t.items()}
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        net.compute_dtype = dt
+        runs = []
+        for _ in range(2 if dt == torch.bfloat16 else 1):
+            net.zero_grad(set_to_none=True)
+            o = net(x)
+            loss = oracle.train_loss(o, t, c["tasks"])
+            loss.backward()
+            runs.append(({k: v.detach().clone() for k, v in o.items()}, loss.item(),
+                         {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+        if len(runs) == 2:
+            assert all(torch.equal(runs[0][0][k], runs[1][0][k]) for k in runs[0][0]), c
+            assert all(torch.equal(runs[0][2][n], runs[1][2][n]) for n in runs[0][2]), c
+        res[dt] = runs[0]
+        net._plans = {k: v for k, v in net._plans.items() if v.dtype != torch.float32}      # free the fp32 buffers
+        torch.cuda.empty_cache()
+    lo, hi = res[torch.bfloat16], res[torch.float32]
+    for k in hi[0]:
+        assert rel_l2(lo[0][k], hi[0][k]) < 6e-2, (c, k, rel_l2(lo[0][k], hi[0][k]))
+    assert abs(lo[1] - hi[1]) < 3e-2 * max(1.0, abs(hi[1]))
+    assert set(lo[2]) == set(hi[2])
+    top = sorted(hi[2], key=lambda n: -hi[2][n].norm().item())[:6]
+    for n in top:
+        a, b = lo[2][n].double().flatten(), hi[2][n].double().flatten()
+        cos = (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
+        assert torch.isfinite(lo[2][n]).all() and cos > 0.7, (c, n, cos)
