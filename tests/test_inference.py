@@ -168,3 +168,49 @@ def test_output_store_layout_matches_the_reference_rules(tmp_path, monkeypatch):
     assert np.array_equal(zarr_lite.open(os.path.join(store, "normals_count"))[:, :, :], cnt)
     with pytest.raises(FileExistsError):
         runner.write_store(None, str(tmp_path / "out"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(8))
+def test_random_volumes_match_the_oracle(i):
+    """randomized version of the pipeline test: volume extents (at, just above and far above the patch, per axis), overlap,
+    batch size (full and ragged last batch), 1-2 input channels, sigmoid / softmax / raw heads -- blended float volumes to 2e-4,
+    the integer casts to 1 level"""
+    import random
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
+    from mt3d_amd.engine import lib
+    lib.require_device()
+    inf = _product()
+    rng = random.Random(1000 + i)
+    patch = tuple(rng.choice([8, 16]) for _ in range(3))
+    cin = rng.choice([1, 2])
+    tasks = {"a": {"channels": rng.choice([1, 2, 3]), "activation": rng.choice(["sigmoid", "softmax", "none"])}}
+    if tasks["a"]["channels"] == 1 and tasks["a"]["activation"] == "softmax":
+        tasks["a"]["activation"] = "sigmoid"
+    if rng.random() < 0.5:
+        tasks["b"] = {"channels": 3, "activation": "none"}
+    mgr = oracle.make_mgr(patch, tasks, cin, 2, True, {})
+    torch.manual_seed(3 + i)
+    ref_net = oracle.NetworkFromConfig(mgr).eval()
+    torch.manual_seed(3 + i)
+    net = NetworkFromConfig(mgr).cuda()
+    dims = tuple(p + rng.choice([0, 1, 3, p // 2, p, 2 * p + 5]) for p in patch)
+    overlap = rng.choice([0.25, 0.5, 0.75])
+    bs = rng.choice([1, 2, 3, 4])
+    vol = torch.rand((cin, *dims), generator=torch.Generator().manual_seed(5 + i))
+    got = inf.SlidingWindowInferer(net, tasks, patch, batch_size=bs, overlap=overlap, compute_dtype=torch.float32)(vol)
+    pos = inf.all_positions(dims, patch, overlap)
+
+    def predict(patches):
+        with torch.no_grad():
+            ref_net.train()          # logits (the activation is the inference loop's job)
+            out = ref_net(torch.from_numpy(patches))
+        return {k: v.numpy() for k, v in out.items()}
+    blended, final = ioracle.sliding_window(vol.numpy(), predict, tasks, patch, bs, pos)
+    for name in tasks:
+        assert got[name].shape == blended[name].shape, (dims, patch)
+        err = np.abs(got[name] - blended[name]).max()
+        assert err < 2e-4, (name, err, dims, patch, overlap, bs)
+        d = np.abs(got[name + "_final"].astype(np.int64) - final[name].astype(np.int64)).max()
+        assert d <= 1, (name, d)
