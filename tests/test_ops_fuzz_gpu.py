@@ -158,3 +158,58 @@ def test_random_instnorm_act(ops, dtype, i):
     if with_res:
         want = rr.grad + (rbase if acc_res else 0)
         assert rel(dres.to_ncdhw(), want) < 3 * TOL[dtype], ("dres", c, dims, n)
+
+
+# ---- fused entry points == their unfused sequences, at random extents around the sizes where the dispatch changes --------------
+def fused_draws(n=20):
+    rng = random.Random(int(os.environ.get("RX_FUZZ_SEED", "31337")) + 3)
+    out = []
+    for _ in range(n):
+        c = rng.choice([32, 32, 64, 64, 128])
+        dims = (rng.choice([4, 8, 12, 14, 16, 20, 30]), rng.choice([8, 16, 20, 32, 36]), rng.choice([16, 16, 32, 48, 64, 24, 8]))
+        out.append((c, dims, rng.choice([1, 2, 3]), rng.choice([0.01, 0.0, 1.0]), rng.random() < 0.5))
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("i", range(20))
+def test_random_fused_conv_norm_entry_points(ops, dtype, i):
+    """rx_conv3d_fwd_stats == conv + stats (same y, same statistics to round-off); rx_conv3d_bwd_data_instats == the plain data
+    gradient (same dx bit for bit) and, when it reports `fused`, the two InstanceNorm-backward means of the two-pass reduction;
+    rx_instnorm_act_pool_fwd == apply + pool bit for bit -- whatever kernel the extent selects"""
+    c, dims, n, slope, acc = fused_draws()[i]
+    k, s = (3, 3, 3), (1, 1, 1)
+    x = to_act(ops, rnd((n, c, *dims), dtype, seed=31 + i), dtype)
+    w = rnd((c, c, 3, 3, 3), torch.float32, seed=32 + i, scale=(27 * c) ** -0.5).float().cuda()
+    wf, wb = ops.pack_conv_weight(w, dtype)
+    y1, y2 = ops.Act.empty(n, *dims, c, dtype), ops.Act.empty(n, *dims, c, dtype)
+    s1, s2 = torch.empty((n, c, 2), device="cuda"), torch.empty((n, c, 2), device="cuda")
+    ops.conv3d_fwd(x, wf, None, y1, k, s)
+    ops.instnorm_stats(y1, s1)
+    ops.conv3d_fwd_stats(x, wf, None, y2, k, s, s2)
+    assert torch.equal(y1.t, y2.t), (c, dims, n, last_kernel(ops))
+    assert torch.allclose(s1, s2, rtol=5e-5, atol=5e-6), ((s1 - s2).abs().max().item(), c, dims, n)
+    # data gradient with the InstanceNorm-backward sums of the layer that produced x
+    g = to_act(ops, rnd((n, c, *dims), dtype, seed=33 + i, scale=0.2), dtype)
+    base = rnd((n, c, *dims), dtype, seed=34 + i, scale=0.1)
+    dx1, dx2 = to_act(ops, base, dtype), to_act(ops, base, dtype)
+    m12 = torch.full((n, c, 2), float("nan"), device="cuda")
+    ops.conv3d_bwd_data(g, wb, dx1, k, s, acc)
+    fused = ops.conv3d_bwd_data_instats(g, wb, dx2, k, s, acc, y1, s1, slope, m12)
+    assert torch.equal(dx1.t, dx2.t), (c, dims, n, acc)
+    d1, d2 = ops.Act.empty(n, *dims, c, dtype), ops.Act.empty(n, *dims, c, dtype)
+    ops.instnorm_act_bwd(dx1, y1, s1, None, d1, slope)
+    if fused:
+        ops.instnorm_act_bwd_apply(dx2, y1, s1, None, d2, m12, slope)
+        a_, b_ = d2.tensor().double(), d1.tensor().double()
+        assert ((a_ - b_).norm() / b_.norm().clamp_min(1e-30)).item() < 5e-3, (c, dims, n, slope)
+    # block epilogue + pool of the next skip path
+    if all(d % 2 == 0 for d in dims):
+        res = to_act(ops, rnd((n, c, *dims), dtype, seed=35 + i), dtype)
+        pd = tuple(d // 2 for d in dims)
+        o1, o2 = ops.Act.empty(n, *dims, c, dtype), ops.Act.empty(n, *dims, c, dtype)
+        p1, p2 = ops.Act.empty(n, *pd, c, dtype), ops.Act.empty(n, *pd, c, dtype)
+        ops.instnorm_act_fwd(y1, s1, o1, 0.01, res)
+        ops.avgpool_fwd(o1, p1, (2, 2, 2))
+        ops.instnorm_act_pool_fwd(y1, s1, o2, p2, (2, 2, 2), 0.01, res)
+        assert torch.equal(o1.t, o2.t) and torch.equal(p1.t, p2.t), (c, dims, n)
