@@ -188,7 +188,8 @@ int rx_instnorm_act_pool_fwd(rx_dtype dt, const rx_act* y, const float* stats, c
 int rx_avgpool_bwd(rx_dtype dt, const rx_act* dy, const rx_act* dx, const int32_t stride[3], int accumulate,
                    void* stream);
 
-/* ---- stem: first Conv3d on the NCDHW fp32 image, Cin <= 8 (encoder.py:84; MFMA kernels for Cin <= 4) ---- */
+/* ---- stem: first Conv3d on the NCDHW fp32 image, Cin <= 16 with Cout * Cin * taps * 4 <= 160 KB (encoder.py:84; MFMA kernels
+ *      for Cin <= 4, VALU kernels with all weights in LDS above) ---- */
 int rx_stem_conv_fwd(rx_dtype dt, const float* x_ncdhw, int n, int cin, int z, int y, int x, const float* w,
                      const float* bias, const rx_act* out, const int32_t kernel[3], void* stream);
 size_t rx_stem_conv_bwd_weight_workspace(int cin, int cout, int taps);

@@ -1480,7 +1480,7 @@ extern "C" int rx_instnorm_act_bwd_head(rx_dtype dt, const float* dout_ncdhw, in
   return RX_OK;
 }
 
-// ---- stem convolution on the NCDHW fp32 image (Cin <= 8; the MFMA variants of rx_stem_wgrad.hip take Cin <= 4) -----------
+// ---- stem convolution on the NCDHW fp32 image (Cin <= 16; the MFMA variants of rx_stem_wgrad.hip take Cin <= 4) ----------
 // thread -> (voxel, vector of P output channels); weights in LDS as [tap*Cin][Cout]
 template <typename T>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, int Cin, int Z, int Y, int X, const float* __restrict__ w,
@@ -1604,7 +1604,18 @@ extern "C" int rx_stem_conv_fwd(rx_dtype dt, const float* x_ncdhw, int n, int ci
   int rc;
   if ((rc = check_vec_channels(out, dt, "rx_stem_conv_fwd(out)"))) return rc;
   if ((rc = check_kernel13(kernel, "rx_stem_conv_fwd"))) return rc;
-  if (!x_ncdhw || !w || cin < 1 || cin > 8) RX_FAIL(RX_EUNSUPPORTED, "rx_stem_conv_fwd: 1 <= Cin <= 8");
+  if (!x_ncdhw || !w || cin < 1 || cin > 16) RX_FAIL(RX_EUNSUPPORTED, "rx_stem_conv_fwd: 1 <= Cin <= 16");
+  {      // the VALU kernels keep all weights in LDS: [Cin * taps][Cout] floats
+    const size_t wl = (size_t)out->c * cin * kernel[0] * kernel[1] * kernel[2] * sizeof(float);
+    if (wl > 160 * 1024) RX_FAIL(RX_EUNSUPPORTED, "rx_stem_conv_fwd: %d x %d channels x %d taps do not fit the LDS", cin, out->c, kernel[0] * kernel[1] * kernel[2]);
+    if (wl > 48 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd32_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd32_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+  }
   if (out->n != n || out->z != z || out->y != y || out->x != x) RX_FAIL(RX_EINVAL, "rx_stem_conv_fwd: geometry mismatch");
   hipStream_t st = (hipStream_t)stream;
   const int TT = kernel[0] * kernel[1] * kernel[2];
@@ -1743,7 +1754,7 @@ extern "C" int rx_stem_conv_bwd_weight(rx_dtype dt, const float* x_ncdhw, int n,
   int rc;
   if ((rc = check_vec_channels(dy, dt, "rx_stem_conv_bwd_weight(dy)"))) return rc;
   if ((rc = check_kernel13(kernel, "rx_stem_conv_bwd_weight"))) return rc;
-  if (!x_ncdhw || !dw || !ws || cin < 1 || cin > 8) RX_FAIL(RX_EUNSUPPORTED, "rx_stem_conv_bwd_weight: 1 <= Cin <= 8");
+  if (!x_ncdhw || !dw || !ws || cin < 1 || cin > 16) RX_FAIL(RX_EUNSUPPORTED, "rx_stem_conv_bwd_weight: 1 <= Cin <= 16");
   const int Co = dy->c;
   if (Co > 64 || Co % 4 || 64 % (Co / 4)) RX_FAIL(RX_EUNSUPPORTED, "rx_stem_conv_bwd_weight: Cout must be 4,8,16,32 or 64 (got %d)", Co);
   if (dy->n != n || dy->z != z || dy->y != y || dy->x != x) RX_FAIL(RX_EINVAL, "rx_stem_conv_bwd_weight: geometry mismatch");

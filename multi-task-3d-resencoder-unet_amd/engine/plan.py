@@ -313,8 +313,11 @@ class Plan:
         kshape = tuple(conv.weight.shape[2:])
         b_k = self._shadow(conv.bias, (cout_p,), [((slice(0, cout),), (slice(None),))])
         if first_of_net:
-            if cin > 8 or any(s != 1 for s in stride):
-                raise UnsupportedConfig("the first convolution reads the NCDHW image: needs in_channels <= 8, stride 1")
+            if cin > 16 or any(s != 1 for s in stride):
+                raise UnsupportedConfig("the first convolution reads the NCDHW image: needs in_channels <= 16, stride 1")
+            if cin > 4 and cout_p * cin * kernel[0] * kernel[1] * kernel[2] * 4 > 160 * 1024:
+                raise UnsupportedConfig(f"the first convolution ({cin} -> {cout} channels, {kernel} kernel) does not fit the LDS of the "
+                                        "first-layer kernels")
             if cout_p > 64:
                 raise UnsupportedConfig(f"the first convolution writes {cout} channels (its weight-gradient kernel holds <= 64)")
             w_k = self._shadow(conv.weight, (cout_p, cin, *kshape), [((slice(0, cout),), (slice(None),))])

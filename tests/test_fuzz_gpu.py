@@ -1,6 +1,6 @@
 """GPU (-m gpu): randomized differential test over the reference's config surface -- 36 small networks drawn from a fixed
 generator (encoder block type, decoder block type, feature counts on and off the 32-channel tile, blocks per stage, per-axis
-kernels / strides, conv_bias, SqueezeExcite, do_stem, 2-D / 3-D, 1-8 input channels, 1-20 output classes with and without
+kernels / strides, conv_bias, SqueezeExcite, do_stem, 2-D / 3-D, 1-16 input channels, 1-20 output classes with and without
 softmax, batch 1-3, ReLU / LeakyReLU, decoder convs per stage) against the CPU oracle in fp32 mode.  Logits carry the 2e-4 bar;
 the data seeds are not curated for LeakyReLU mask margin, so gradients are checked by magnitude and direction (a mask flip moves a
 tensor by 1e-3..2e-2, a wiring bug by O(1)): cosine > 0.99 and norm ratio within 3 % (0.9971 seen on a 4-stage BottleneckD draw), for every parameter that has a gradient --
@@ -54,7 +54,7 @@ def draw(rng):
     tasks = {"t": {"channels": classes, "activation": act, "weight": 1, "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
     if rng.random() < 0.3:
         tasks["n"] = {"channels": 3, "activation": "none", "weight": 0.5, "loss_fn": "MaskedCosineLoss"}
-    return dict(patch=patch, cin=rng.choice([1, 1, 2, 3, 6, 8]), batch=rng.choice([1, 2, 3]), mc=mc, tasks=tasks)
+    return dict(patch=patch, cin=rng.choice([1, 1, 2, 3, 6, 8, 12, 16]), batch=rng.choice([1, 2, 3]), mc=mc, tasks=tasks)
 
 
 def configs(n=36, seed=20260):

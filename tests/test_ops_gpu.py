@@ -264,7 +264,8 @@ def test_avgpool(ops, dtype, s):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,k", [(1, (3, 3, 3)), (2, (3, 3, 3)), (1, (1, 3, 3)), (4, (3, 3, 3)), (5, (3, 3, 3)), (8, (3, 3, 3)),   # > 4: VALU kernels
-                                   (6, (1, 3, 3)), (8, (3, 1, 3)), (5, (1, 1, 1)), (4, (1, 1, 1)), (8, (3, 3, 1))])   # few taps x > 4 channels (fuzz find)
+                                   (6, (1, 3, 3)), (8, (3, 1, 3)), (5, (1, 1, 1)), (4, (1, 1, 1)), (8, (3, 3, 1)),    # few taps x > 4 channels (fuzz find)
+                                   (12, (3, 3, 3)), (16, (3, 3, 3)), (16, (1, 3, 3))])                               # weights beyond 48 KB of LDS
 def test_stem(ops, dtype, cin, k):
     n, co, dims = 2, 32, (6, 9, 10)
     x = rnd((n, cin, *dims), torch.float32, 14)
