@@ -176,7 +176,7 @@ BASE = dict(patch=(32, 32, 32), batch=1, tasks=["sheet"], dtype=torch.bfloat16, 
     ("se_accumulate_no_sync", dict(port_salt=4, micro_batches=2, model_config={"squeeze_excitation": True})),
     # 24/48/80 features: padded buffers + shadow parameters; the padded gradients are sliced and announced to the synchroniser
     # after the backward list (engine/plan.py::_backward_finish), not from inside it
-    ("padded_channels_se_bf16", dict(port_salt=6, patch=(16, 16, 16), batch=2, autoconfigure=False, bucket_bytes=256 << 10,
+    ("padded_channels_se_bf16", dict(port_salt=6, patch=(16, 16, 16), batch=2, autoconfigure=False, bucket_bytes=256 << 10, micro_batches=2,
                                      model_config=dict(basic_encoder_block="BasicBlockD", basic_decoder_block="ConvBlock",
                                                        bottleneck_block="BasicBlockD", features_per_stage=[24, 48, 80], num_stages=3,
                                                        n_blocks_per_stage=[1, 2, 2], kernel_sizes=[3, 3, 3],
