@@ -1,7 +1,7 @@
-"""first layer where the 16-bit engine leaves the fp32 engine: python scripts/layer_diff.py <fuzz index> [bf16|fp16] [medium]"""
+"""TEST-SIDE DEBUGGING TOOL (imports the randomized test's draws).  First layer where the 16-bit engine leaves the fp32 engine: python tests/layer_diff.py <fuzz index> [bf16|fp16] [medium]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]      # (test_fuzz_gpu imports the oracle)
 import torch
 import mt3d_amd  # noqa
 from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
