@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["rx_elementwise.hip", "rx_igemm.hip", "rx_wgrad.hip", "rx_wgrad_halo.hip", "rx_conv_halo.hip", "rx_stem_wgrad.hip", "rx_loss.hip", "rx_se.hip", "rx_dgrad_s2.hip", "rx_prog.hip"]
+SOURCES = ["rx_elementwise.hip", "rx_igemm.hip", "rx_wgrad.hip", "rx_wgrad_halo.hip", "rx_conv_halo.hip", "rx_stem_wgrad.hip", "rx_loss.hip", "rx_se.hip", "rx_dgrad_s2.hip", "rx_prog.hip", "rx_pointwise.hip"]
 HEADERS = ["rx_common.h", "rx_prog.h", os.path.join("..", "..", "include", "rxunet.h")]
 LIB = os.path.join(HERE, "librxunet.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -539,6 +539,9 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
                      void* ws, size_t ws_bytes, hipStream_t st, float* stat_part, size_t stat_bytes, int* stat_chunks,
                      const RxBwdStat* bs);
 void rx_inbwd_fused_finalize_launch(const float* partial, int N, int nchunks, int C, double V, const float* stats, float* m12, hipStream_t st);
+// rx_pointwise.hip
+int rx_pointwise_try(rx_dtype dt, const rx_act* in, const void* w, const float* bias, const rx_act* out, const int32_t stride[3],
+                     int accumulate, hipStream_t st);
 // rx_dgrad_s2.hip
 int rx_dgrad_s2_halo_try(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx, int accumulate, hipStream_t st);
 // rx_elementwise.hip
@@ -580,6 +583,13 @@ extern "C" int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, co
     if (rc == 1) return RX_OK;
   }
   if (x->cs) RX_FAIL(RX_EUNSUPPORTED, "rx_conv3d_fwd: a planar-concat input needs the 3x3x3 stride-1 halo kernel (Co = 32, X >= 16)");
+  if (kernel[0] == 1 && kernel[1] == 1 && kernel[2] == 1 && stride[0] == 1 && stride[1] == 1 && stride[2] == 1) {
+    const int32_t one[3] = {1, 1, 1};
+    if (rx_pointwise_try(dt, x, w_fwd, bias, y, one, 0, (hipStream_t)stream) == 1) {      // streaming kernel, no spatial footprint
+      RX_CHECK_LAUNCH("rx_conv3d_fwd(pointwise)");
+      return RX_OK;
+    }
+  }
   IgemmGeom g;
   memset(&g, 0, sizeof(g));
   geom_in(g, x);
@@ -686,6 +696,13 @@ extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_b
     if (rc == 1) return RX_OK;
   }
   if (dx->cs) RX_FAIL(RX_EUNSUPPORTED, "rx_conv3d_bwd_data: a planar-concat dx needs the wave-specialised 64-channel halo kernel");
+  if (kernel[0] == 1 && kernel[1] == 1 && kernel[2] == 1 && stride[0] == 1 && stride[1] == 1 && stride[2] == 1) {
+    const int32_t one[3] = {1, 1, 1};
+    if (rx_pointwise_try(dt, dy, w_bwd, nullptr, dx, one, accumulate, (hipStream_t)stream) == 1) {
+      RX_CHECK_LAUNCH("rx_conv3d_bwd_data(pointwise)");
+      return RX_OK;
+    }
+  }
   if (kernel[0] == 3 && kernel[1] == 3 && kernel[2] == 3 && stride[0] == 2 && stride[1] == 2 && stride[2] == 2) {
     rc = rx_dgrad_s2_halo_try(dt, dy, w_bwd, dx, accumulate, (hipStream_t)stream);   // LDS-halo kernel, all 8 parity classes
     if (rc < 0) return rc;
@@ -747,6 +764,10 @@ extern "C" int rx_convT3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, c
   if (!rx_act_ok(x) || !rx_act_ok(y) || !w_fwd) RX_FAIL(RX_EINVAL, "rx_convT3d_fwd: bad arguments");
   int rc = checkT(stride, x, y, "rx_convT3d_fwd");
   if (rc) return rc;
+  if (rx_pointwise_try(dt, x, w_fwd, bias, y, stride, 0, (hipStream_t)stream) == 1) {       // x once, y once (rx_pointwise.hip)
+    RX_CHECK_LAUNCH("rx_convT3d_fwd(pointwise)");
+    return RX_OK;
+  }
   // y[i*s + t] = sum_ci x[i] W[ci][co][t] + b : one single-tap PHASE per kernel position t, one launch
   IgemmGeom g;
   memset(&g, 0, sizeof(g));

@@ -59,6 +59,7 @@ CONV_CASES = [
     (64, 64, (14, 32, 64), (3, 3, 3), (1, 1, 1)),     # >= 256 tiles, 64 channels: wave-specialised producer/consumer kernel
     (128, 64, (32, 32, 64), (3, 3, 3), (2, 2, 2)),    # stride-2 data gradient on the parity-class halo kernel (64 dY channels)
     (128, 64, (24, 40, 72), (3, 3, 3), (2, 2, 2)),    # same, ragged dY tiles
+    (64, 128, (12, 20, 18), (1, 1, 1), (1, 1, 1)),    # 1x1x1 projection above 4096 voxels: the streaming pointwise kernel (fwd and bwd-data)
 ]
 
 
@@ -73,6 +74,7 @@ EXPECT_KERNELS = {
     (64, 64, (14, 32, 64), (3, 3, 3), (1, 1, 1)): ("conv_halo64ws_kernel", "conv_halo64ws_kernel", "wgrad_halo16ws_kernel"),
     (128, 64, (32, 32, 64), (3, 3, 3), (2, 2, 2)): (None, "dgrad_s2p_kernel", None),
     (128, 64, (24, 40, 72), (3, 3, 3), (2, 2, 2)): (None, "dgrad_s2p_kernel", None),
+    (64, 128, (12, 20, 18), (1, 1, 1), (1, 1, 1)): ("pointwise_kernel", "pointwise_kernel", None),
 }
 
 
@@ -130,6 +132,9 @@ CONVT_CASES = [
     (128, 64, (3, 5, 6), (2, 2, 2)),
     (64, 64, (4, 6, 6), (1, 2, 2)),
     (512, 256, (2, 2, 2), (2, 2, 2)),
+    (64, 32, (12, 18, 20), (2, 2, 2)),         # >= 4096 voxels: the streaming pointwise kernel (x once, y once)
+    (256, 128, (8, 9, 16), (2, 2, 2)),         # 8 taps x 256 channels: 132 KB of weights would leave one workgroup per CU -> gather kernel
+    (128, 64, (10, 16, 24), (1, 2, 2)),        # anisotropic stride
 ]
 
 
@@ -152,6 +157,8 @@ def test_convT3d_fwd_bwd(ops, dtype, case):
     # write straight into channels [0, co) of a 2*co-wide concat buffer (decoder.py:146-147)
     cat = ops.Act(torch.full((n, *odims, 2 * co), 3.0, dtype=dtype, device="cuda"))
     ops.convT3d_fwd(xa, w_fwd, b.float().cuda(), cat.slice(0, co), s)
+    if dtype != torch.float32 and n * dims[0] * dims[1] * dims[2] >= 4096 and ci <= 128:
+        assert last_kernel(ops) == "pointwise_kernel"
     assert rel(cat.slice(0, co).to_ncdhw(), y_ref.detach()) < TOL[dtype]
     assert torch.all(cat.slice(co, co).tensor() == 3.0)              # the skip half is untouched
 

@@ -88,10 +88,10 @@ def test_unsupported_configs_fail_loudly(NetworkFromConfig):
     with pytest.raises((UnsupportedConfig, ValueError, KeyError, AttributeError, TypeError)):
         net = NetworkFromConfig(mgr).cuda()
         net(torch.zeros(1, 1, 16, 16, 16, device="cuda"))
-    mgr = oracle.make_mgr((16, 16, 16), ONE, 9, 1, True, {})
+    mgr = oracle.make_mgr((16, 16, 16), ONE, 17, 1, True, {})                              # (up to 16 input channels run)
     net = NetworkFromConfig(mgr).cuda()
     with pytest.raises(UnsupportedConfig):
-        net(torch.zeros(1, 9, 16, 16, 16, device="cuda"))
+        net(torch.zeros(1, 17, 16, 16, 16, device="cuda"))
 
 
 def test_droppath_training_and_eval(NetworkFromConfig):
