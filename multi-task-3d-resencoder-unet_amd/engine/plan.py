@@ -300,6 +300,11 @@ class Plan:
         cin, cout = conv.in_channels, conv.out_channels
         cout_p = self._cp(cout)
         first_of_net = first_of_net or x is None      # x is None: the layer reads the NCDHW image (the stem; without one, the first block)
+        if first_of_net and any(s != 1 for s in stride):
+            # a strided first layer (do_stem=False with strides[0] != 1): the first-layer kernels read the image at stride 1 only --
+            # convert the image to the channels-last layout (padded to 32 channels) and run the ordinary strided convolution on it
+            x = self._image_act(tape)
+            first_of_net = False
         in_dims = x.act.dims[1:] if not first_of_net else self.spatial
         odims = self._out_dims(in_dims, kernel, stride)
         y = self._new(odims, cout_p, f"y:{len(tape)}")
@@ -346,6 +351,21 @@ class Plan:
             self._drops.append(drop)
         tape.append(Rec("inact", dict(y=y, stats=stats, eps=eps, res=residual, out=out, slope=slope, gate=gate, drop=drop)))
         return out
+
+    def _image_act(self, tape):
+        if getattr(self, "_image_at", None) is not None:
+            return self._image_at
+        cin = self.Cin
+        if cin > 16:
+            raise UnsupportedConfig("the first-layer kernels read at most 16 input channels")
+        cp = self._cp(cin)
+        y = self._new(self.spatial, cp, "image", needs_grad=False)
+        eye = torch.zeros((cp, cin, 1, 1, 1), dtype=torch.float32, device=self.device)
+        if self.device.type != "meta":
+            eye[torch.arange(cin), torch.arange(cin)] = 1.0
+        tape.append(Rec("image", dict(y=y, w=eye)))
+        self._image_at = y
+        return y
 
     def _draw_dropout(self, d):
         """this step's kept (n, c) planes of one dropout layer: 1 / 0, in place (bernoulli(1 - p) as torch's feature dropout)"""
@@ -416,17 +436,15 @@ class Plan:
     def _emit_block(self, tape, blk, x: AT, out: Optional[AT] = None):
         """BasicBlockD / BottleneckD: skip path, main path, fused `nonlin(IN(conv_k(..)) + skip)`."""
         r = x
-        if x is None and not any(hasattr(op, "spec") for op in blk.skip_ops):
-            raise UnsupportedConfig("do_stem=False: the first block adds the raw image to its output (identity / pooled skip); "
-                                    "the HIP path needs a projection on the skip path")
+        if x is None and (not blk.skip_ops or isinstance(blk.skip_ops[0], (nn.AvgPool3d, nn.AvgPool2d))):
+            # do_stem=False and the first block adds (or pools) the RAW image on its skip path: bring the image into the engine's
+            # channels-last layout with the first-layer kernel and an identity 1x1x1 weight (a constant, not a parameter)
+            r = self._image_act(tape)
         for op in blk.skip_ops:
             if isinstance(op, (nn.AvgPool3d, nn.AvgPool2d)):
-                if r is None:
-                    raise UnsupportedConfig("do_stem=False with a strided first block: the image would be pooled on the skip path "
-                                            "(the first-layer kernel reads the NCDHW image at stride 1)")
                 st = self._k3(op.stride if isinstance(op.stride, (list, tuple)) else [op.stride] * (2 if self.two_d else 3))
                 odims = tuple(d // s for d, s in zip(r.act.dims[1:], st))
-                p = self._new(odims, r.act.c, f"pool:{len(tape)}")
+                p = self._new(odims, r.act.c, f"pool:{len(tape)}", needs_grad=r.needs_grad)
                 tape.append(Rec("pool", dict(x=r, y=p, stride=st)))
                 r = p
             else:
@@ -609,6 +627,8 @@ class Plan:
                 a = rec.a
                 if rec.kind == "stem":
                     f.append(lambda a=a: ops.stem_conv_fwd(P._x, a["w"], a["b"], a["y"].act, a["kernel"]))
+                elif rec.kind == "image":        # NCDHW fp32 image -> channels-last compute type (identity 1x1x1 first-layer conv)
+                    f.append(lambda a=a: ops.stem_conv_fwd(P._x, a["w"], None, a["y"].act, [1, 1, 1]))
                 elif rec.kind == "conv":
                     def cstep(a=a):
                         P._await_pack(a["pk"])
@@ -805,7 +825,7 @@ class Plan:
                     dy = self._dy_for(y)
                     y.gact = dy
                     gres, acc = None, False
-                    if res is not None:
+                    if res is not None and res.needs_grad:        # (the converted image of a stem-less net needs no gradient)
                         gres = self._grad_buf(res)
                         acc = view_written(res)
                         res.written = True
@@ -888,7 +908,7 @@ class Plan:
                         side_run(launches, dy)
                     order += [a["widx"]] + ([a["bidx"]] if a["bidx"] is not None else [])
                     b.append(wstep)
-                    if rec.kind == "conv":
+                    if rec.kind == "conv" and a["x"].needs_grad:
                         x = a["x"]
                         gx = self._grad_buf(x)
                         acc = view_written(x)
@@ -934,6 +954,8 @@ class Plan:
                     b.append(step)
                 elif rec.kind == "pool":
                     x, y = a["x"], a["y"]
+                    if not x.needs_grad:
+                        continue
                     gx = self._grad_buf(x)
                     acc = view_written(x)
                     x.written = True

@@ -30,7 +30,7 @@ def draw(rng):
         k = [rng.choice([1, 3]) if aniso and s == 0 else 3 for _ in range(nd)]
         if all(v == 1 for v in k):
             k[-1] = 3          # (a 1x1x1 first layer on one input channel makes every channel the same affine map: ill-conditioned in 16 bits)
-        st = [1] * nd if s == 0 else [rng.choice([1, 2]) if aniso else 2 for _ in range(nd)]
+        st = ([2] * nd if rng.random() < 0.15 else [1] * nd) if s == 0 else [rng.choice([1, 2]) if aniso else 2 for _ in range(nd)]
         if s > 0 and all(v == 1 for v in st):
             st[-1] = 2
         kernels.append(k), strides.append(st)
@@ -55,6 +55,12 @@ def draw(rng):
     if rng.random() < 0.3:
         tasks["n"] = {"channels": 3, "activation": "none", "weight": 0.5, "loss_fn": "MaskedCosineLoss"}
     return dict(patch=patch, cin=rng.choice([1, 1, 2, 3, 6, 8, 12, 16]), batch=rng.choice([1, 2, 3]), mc=mc, tasks=tasks)
+
+
+def targets_for(c, outputs, seed):
+    """targets at the OUTPUT extent (a strided first stage shrinks it: the reference's heads then live on the coarser grid)"""
+    osp = tuple(next(iter(outputs.values())).shape[2:])
+    return oracle.synthetic_batch(c["batch"], c["cin"], osp, c["tasks"], seed)[1]
 
 
 def configs(n=36, seed=20260):
@@ -95,6 +101,7 @@ def test_random_config_matches_the_oracle(NetworkFromConfig, i):
         pytest.skip(f"loudly rejected: {e}")
     for k in o_r:
         assert rel_l2(o_n[k].cpu(), o_r[k].detach()) < 2e-4, (c, k)
+    t = targets_for(c, o_r, 7 + i)
     l_r = oracle.train_loss(o_r, t, c["tasks"])
     l_n = oracle.train_loss(o_n, {k: v.cuda() for k, v in t.items()}, c["tasks"])
     assert abs(l_r.item() - l_n.item()) < 1e-4 * max(1.0, abs(l_r.item()))
@@ -134,12 +141,17 @@ def test_random_config_low_precision_modes(NetworkFromConfig, i, dtype):
     net.compute_dtype = dtype
     x, t = oracle.synthetic_batch(c["batch"], c["cin"], c["patch"], c["tasks"], 7 + i)
     o_r = ref(x)
+    t = targets_for(c, o_r, 7 + i)
     l_r = oracle.train_loss(o_r, t, c["tasks"])
     l_r.backward()
     runs = []
+    from mt3d_amd.engine.plan import UnsupportedConfig
     for _ in range(2):
         net.zero_grad(set_to_none=True)
-        o_n = net(x.cuda())
+        try:
+            o_n = net(x.cuda())
+        except UnsupportedConfig as e:
+            pytest.skip(f"loudly rejected: {e}")
         l_n = oracle.train_loss(o_n, {k: v.cuda() for k, v in t.items()}, c["tasks"])
         l_n.backward()
         runs.append(({k: v.detach().clone() for k, v in o_n.items()}, {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
@@ -282,7 +294,10 @@ def test_random_config_with_channel_dropout(NetworkFromConfig, i):
     orig = plan_mod.Plan._draw_dropout
     plan_mod.Plan._draw_dropout = draw_mask
     try:
-        o_n = net(x.cuda())
+        try:
+            o_n = net(x.cuda())
+        except plan_mod.UnsupportedConfig as e:
+            pytest.skip(f"loudly rejected: {e}")
         plan = next(iter(net._plans.values()))
         # the oracle's dropout modules in execution order; module k multiplies by mask k / (1 - p) on its real channels
         mods = []
@@ -304,6 +319,7 @@ def test_random_config_with_channel_dropout(NetworkFromConfig, i):
         o_r = ref(x)
         for k in o_r:
             assert rel_l2(o_n[k].cpu(), o_r[k].detach()) < 2e-4, (c, k, rel_l2(o_n[k].cpu(), o_r[k].detach()))
+        t = targets_for(c, o_r, 7 + i)
         l_r = oracle.train_loss(o_r, t, c["tasks"])
         l_n = oracle.train_loss(o_n, {k: v.cuda() for k, v in t.items()}, c["tasks"])
         l_r.backward()
