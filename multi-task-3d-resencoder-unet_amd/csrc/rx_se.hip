@@ -141,6 +141,56 @@ __device__ inline void se_gather_line(const float* __restrict__ part, int n, int
   __syncthreads();
 }
 
+// The two small matrix-vector products of a gate kernel.  The deep stages run these kernels with 8-16 workgroups on 512 channels
+// and 32 reduction channels: a chain of dependent scalar loads per row was most of their ~23 us.  Both helpers issue every load of
+// a thread as independent 16-byte loads before the first use.
+//   rows:  out[j] = sum_c W[j*C + c] * v[c],  j < rd      (W row-major over c; v in LDS).  256 / RDP threads share a row.
+template <int RDP>
+__device__ inline void se_mv_rows(const float* __restrict__ W, const float* __restrict__ v, int C, int rd, float* __restrict__ out) {
+  constexpr int TPR = 256 / RDP;                 // threads per row (4 .. 32): consecutive lanes of one wave
+  const int tid = threadIdx.x, j = tid / TPR, part = tid - j * TPR;
+  float a = 0.f;
+  if (j < rd) {
+    const float* wr = W + (size_t)j * C;
+    for (int c0 = part * 4; c0 < C; c0 += TPR * 4 * 4) {
+      f32x4 w4[4], v4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * TPR * 4;
+        w4[u] = c < C ? *reinterpret_cast<const f32x4*>(wr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v4[u] = c < C ? *reinterpret_cast<const f32x4*>(v + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a += w4[u][0] * v4[u][0] + w4[u][1] * v4[u][1] + w4[u][2] * v4[u][2] + w4[u][3] * v4[u][3];
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < TPR; o <<= 1) a += __shfl_xor(a, o, 64);
+  if (part == 0 && j < rd) out[j] = a;
+}
+__device__ inline void se_mv_rows_any(const float* __restrict__ W, const float* __restrict__ v, int C, int rd, float* __restrict__ out) {
+  if (rd <= 8) se_mv_rows<8>(W, v, C, rd, out);
+  else if (rd <= 16) se_mv_rows<16>(W, v, C, rd, out);
+  else if (rd <= 32) se_mv_rows<32>(W, v, C, rd, out);
+  else se_mv_rows<64>(W, v, C, rd, out);
+}
+//   per channel:  sum_j W[c*rd + j] * h[j]  for one channel c (W row-major over j, rd % 4 == 0; h in LDS)
+__device__ inline float se_dot_row(const float* __restrict__ wr, const float* __restrict__ h, int rd) {
+  float z = 0.f;
+  for (int j0 = 0; j0 < rd; j0 += 16) {
+    f32x4 w4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w4[u] = j0 + 4 * u < rd ? *reinterpret_cast<const f32x4*>(wr + j0 + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (j0 + 4 * u < rd) {
+        const f32x4 h4 = *reinterpret_cast<const f32x4*>(h + j0 + 4 * u);
+        z += w4[u][0] * h4[0] + w4[u][1] * h4[1] + w4[u][2] * h4[2] + w4[u][3] * h4[3];
+      }
+  }
+  return z;
+}
+
 // ---- gate forward: grid = (lines, N) ----------------------------------------------------------------------------------
 // LDS: sp[C] | sh[64] | red[256]
 __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restrict__ part, int chunks, int X, int C, int keep_x, float R,
@@ -155,6 +205,8 @@ __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restric
   const int line = blockIdx.x, n = blockIdx.y, L = gridDim.x, tid = threadIdx.x;
   const float s = path_scale ? path_scale[n] : 1.f;
   const size_t row = (size_t)n * L + line;
+  // 16-byte loads of the fc weights: channel counts / reduction widths that are multiples of 4, 16-byte aligned pointers
+  const bool vec_ok = (C % 4 == 0) && (rd % 4 == 0) && !(((uintptr_t)w1 | (uintptr_t)w2) & 15);
   se_gather_line<1>(part, n, chunks, X, C, line, keep_x, sp, red);
   for (int c = tid; c < C; c += 256) {
     const float praw = (sp[c] / R - stats[2 * ((size_t)n * C + c)]) * stats[2 * ((size_t)n * C + c) + 1];
@@ -162,22 +214,36 @@ __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restric
     sp[c] = s * praw;
   }
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
-  for (int j = wave; j < rd; j += 4) {
-    float a = 0.f;
-    for (int c = lane; c < C; c += 64) a += w1[(size_t)j * C + c] * sp[c];
-    a = wave_sum(a);
-    if (lane == 0) {
-      a += b1[j];
+  if (vec_ok) {
+    se_mv_rows_any(w1, sp, C, rd, sh);
+    __syncthreads();
+    if (tid < rd) {
+      float a = sh[tid] + b1[tid];
       a = a > 0.f ? a : 0.f;
-      sh[j] = a;
-      hidden[row * rd + j] = a;
+      sh[tid] = a;
+      hidden[row * rd + tid] = a;
+    }
+  } else {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int j = wave; j < rd; j += 4) {
+      float a = 0.f;
+      for (int c = lane; c < C; c += 64) a += w1[(size_t)j * C + c] * sp[c];
+      a = wave_sum(a);
+      if (lane == 0) {
+        a += b1[j];
+        a = a > 0.f ? a : 0.f;
+        sh[j] = a;
+        hidden[row * rd + j] = a;
+      }
     }
   }
   __syncthreads();
   for (int c = tid; c < C; c += 256) {
     float z = b2[c];
-    for (int j = 0; j < rd; ++j) z += w2[(size_t)c * rd + j] * sh[j];
+    if (vec_ok)
+      z += se_dot_row(w2 + (size_t)c * rd, sh, rd);
+    else
+      for (int j = 0; j < rd; ++j) z += w2[(size_t)c * rd + j] * sh[j];
     const float gt = 1.f / (1.f + expf(-z));
     gate[row * C + c] = gt;
     mult[row * C + c] = s * gt;
@@ -225,20 +291,59 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restric
   }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
-  for (int j = wave; j < rd; j += 4) {
-    float a = 0.f;
-    for (int c = lane; c < C; c += 64) a += w2[(size_t)c * rd + j] * sds[c];
-    a = wave_sum(a);
-    if (lane == 0) {
-      a = hidden[row * rd + j] > 0.f ? a : 0.f;
-      sdh[j] = a;
-      dhm[row * rd + j] = a;
+  if ((rd % 4 == 0) && rd <= 64 && !((uintptr_t)w2 & 15)) {
+    // dh[j] = sum_c W2[c][j] * ds[c]: a thread takes whole ROWS of W2 (16-byte loads, rd contiguous floats per channel) and keeps
+    // rd partial sums; one xor-shuffle tree per j and a cross-wave add finish.  (A wave per j read W2 with a stride of rd floats:
+    // 64 separate cache lines per load instruction.)
+    float pj[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) pj[j] = 0.f;
+    for (int c = tid; c < C; c += 256) {
+      const float d = sds[c];
+      const float* wr = w2 + (size_t)c * rd;
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (4 * q < rd) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + 4 * q);
+          pj[4 * q] += w4[0] * d, pj[4 * q + 1] += w4[1] * d, pj[4 * q + 2] += w4[2] * d, pj[4 * q + 3] += w4[3] * d;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 64; ++j)
+      if (j < rd) {
+        float a = wave_sum(pj[j]);
+        if (lane == 0) red[wave * 64 + j] = a;
+      }
+    __syncthreads();
+    if (tid < rd) {
+      float a = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+      a = hidden[row * rd + tid] > 0.f ? a : 0.f;
+      sdh[tid] = a;
+      dhm[row * rd + tid] = a;
+    }
+  } else {
+    for (int j = wave; j < rd; j += 4) {
+      float a = 0.f;
+      for (int c = lane; c < C; c += 64) a += w2[(size_t)c * rd + j] * sds[c];
+      a = wave_sum(a);
+      if (lane == 0) {
+        a = hidden[row * rd + j] > 0.f ? a : 0.f;
+        sdh[j] = a;
+        dhm[row * rd + j] = a;
+      }
     }
   }
   __syncthreads();
   for (int c = tid; c < C; c += 256) {
     float dp = 0.f;
-    for (int j = 0; j < rd; ++j) dp += w1[(size_t)j * C + c] * sdh[j];
+    for (int j0 = 0; j0 < rd; j0 += 8) {          // 8 coalesced loads in flight (adjacent threads = adjacent channels)
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wv[u] = j0 + u < rd ? w1[(size_t)(j0 + u) * C + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (j0 + u < rd) dp += wv[u] * sdh[j0 + u];
+    }
     const float D = s * dp / R, m = mult[row * C + c];
     dadd[row * C + c] = D;
     line_m[(row * 2 + 0) * C + c] = m * sL1[c] + R * D;
