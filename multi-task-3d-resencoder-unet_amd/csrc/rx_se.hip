@@ -336,12 +336,12 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restric
   __syncthreads();
   for (int c = tid; c < C; c += 256) {
     float dp = 0.f;
-    for (int j0 = 0; j0 < rd; j0 += 8) {          // 8 coalesced loads in flight (adjacent threads = adjacent channels)
-      float wv[8];
+    for (int j0 = 0; j0 < rd; j0 += 32) {         // up to 32 coalesced loads in flight (adjacent threads = adjacent channels)
+      float wv[32];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) wv[u] = j0 + u < rd ? w1[(size_t)(j0 + u) * C + c] : 0.f;
+      for (int u = 0; u < 32; ++u) wv[u] = j0 + u < rd ? w1[(size_t)(j0 + u) * C + c] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 32; ++u)
         if (j0 + u < rd) dp += wv[u] * sdh[j0 + u];
     }
     const float D = s * dp / R, m = mult[row * C + c];
