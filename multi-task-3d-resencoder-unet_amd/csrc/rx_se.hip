@@ -351,6 +351,93 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restric
   }
 }
 
+// ---- gate backward, deep-stage shape (C <= 512, rd <= 32, rd % 4 == 0): every global value a thread needs -- its two channels' gate /
+// mult / pooled, its W2 rows and W1 columns, the hidden row -- is requested BEFORE the partial sums are gathered, so the six phases
+// below only wait for LDS and shuffles.  Same formulas and summation order as se_gate_bwd_kernel: dadd, dz2, dhm come out bit-identical,
+// line_m within one ulp (the compiler fuses a different product of m * L + R * D); scripts/probes/se_bwd_ab.py compares two builds.
+__global__ __launch_bounds__(256) void se_gate_bwd_small_kernel(const float* __restrict__ part, int chunks, int X, int C, int keep_x, float R,
+                                                                const float* __restrict__ path_scale, const float* __restrict__ w1,
+                                                                const float* __restrict__ w2, int rd, const float* __restrict__ pooled,
+                                                                const float* __restrict__ hidden, const float* __restrict__ gate,
+                                                                const float* __restrict__ mult, float* __restrict__ dadd,
+                                                                float* __restrict__ dz2, float* __restrict__ dhm, float* __restrict__ line_m) {
+  extern __shared__ float sm[];
+  float* sL1 = sm;
+  float* sL2 = sm + C;
+  float* sds = sm + 2 * C;
+  float* sdh = sm + 3 * C;
+  float* red = sdh + 64;
+  const int line = blockIdx.x, n = blockIdx.y, L = gridDim.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const float s = path_scale ? path_scale[n] : 1.f;
+  const size_t row = (size_t)n * L + line;
+  // ---- prefetch
+  float gt_r[2], m_r[2], p_r[2], w1c[2][32];
+  f32x4 w2r[2][8];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = tid + 256 * k;
+    const bool on = c < C;
+    gt_r[k] = on ? gate[row * C + c] : 0.f;
+    m_r[k] = on ? mult[row * C + c] : 0.f;
+    p_r[k] = on ? pooled[row * C + c] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w2r[k][q] = (on && 4 * q < rd) ? *reinterpret_cast<const f32x4*>(w2 + (size_t)c * rd + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 32; ++j) w1c[k][j] = (on && j < rd) ? w1[(size_t)j * C + c] : 0.f;
+  }
+  const float hid = tid < rd ? hidden[row * rd + tid] : 0.f;
+  se_gather_line<2>(part, n, chunks, X, C, line, keep_x, sL1, red);     // sL2 = sL1 + C
+  float ds_r[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = tid + 256 * k;
+    ds_r[k] = 0.f;
+    if (c < C) {
+      ds_r[k] = s * sL2[c] * gt_r[k] * (1.f - gt_r[k]);
+      dz2[row * C + c] = ds_r[k];
+    }
+  }
+  float pj[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) pj[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      pj[4 * q] += w2r[k][q][0] * ds_r[k], pj[4 * q + 1] += w2r[k][q][1] * ds_r[k];
+      pj[4 * q + 2] += w2r[k][q][2] * ds_r[k], pj[4 * q + 3] += w2r[k][q][3] * ds_r[k];
+    }
+#pragma unroll
+  for (int j = 0; j < 32; ++j)
+    if (j < rd) {
+      const float a = wave_sum(pj[j]);
+      if (lane == 0) red[wave * 64 + j] = a;
+    }
+  __syncthreads();
+  if (tid < rd) {
+    float a = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+    a = hid > 0.f ? a : 0.f;
+    sdh[tid] = a;
+    dhm[row * rd + tid] = a;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = tid + 256 * k;
+    if (c < C) {
+      float dp = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j)
+        if (j < rd) dp += w1c[k][j] * sdh[j];
+      const float D = s * dp / R;
+      dadd[row * C + c] = D;
+      line_m[(row * 2 + 0) * C + c] = m_r[k] * sL1[c] + R * D;
+      line_m[(row * 2 + 1) * C + c] = m_r[k] * sL2[c] + D * R * p_r[k];
+    }
+  }
+}
+
 // m12[n][c] = (sum_lines t1, sum_lines t2) / V
 __global__ __launch_bounds__(256) void se_m12_kernel(const float* __restrict__ line_m, int N, int L, int C, double V, float* __restrict__ m12) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -628,7 +715,12 @@ extern "C" int rx_se_gate_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, con
                        p.X, y->c, p.rows_per_chunk, slope, part);
   });
   const size_t lds = (size_t)(3 * C + 64 + 512) * sizeof(float);
-  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(p.L, y->n), dim3(256), lds, st, (const float*)part, p.chunks, p.X, y->c, keep_x, p.R, path_scale,
+  if (se && se->w1 && y->c <= 512 && se->rd <= 32 && se->rd % 4 == 0 && !((uintptr_t)se->w2 & 15))
+    hipLaunchKernelGGL(se_gate_bwd_small_kernel, dim3(p.L, y->n), dim3(256), lds, st, (const float*)part, p.chunks, p.X, y->c, keep_x, p.R, path_scale,
+                     se ? se->w1 : (const float*)nullptr, se ? se->w2 : (const float*)nullptr, se ? se->rd : 0, pooled, hidden, gate, mult, dadd, dz2,
+                     dhm, line_m);
+  else
+    hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(p.L, y->n), dim3(256), lds, st, (const float*)part, p.chunks, p.X, y->c, keep_x, p.R, path_scale,
                      se ? se->w1 : (const float*)nullptr, se ? se->w2 : (const float*)nullptr, se ? se->rd : 0, pooled, hidden, gate, mult, dadd, dz2,
                      dhm, line_m);
   hipLaunchKernelGGL(se_m12_kernel, dim3((y->n * y->c + 255) / 256), dim3(256), 0, st, (const float*)line_m, y->n, p.L, y->c,
