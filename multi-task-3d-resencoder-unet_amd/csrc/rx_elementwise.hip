@@ -130,31 +130,45 @@ __global__ __launch_bounds__(256) void colreduce_kernel(Op op, int V, int C, int
 enum { FIN_STATS = 0, FIN_MEAN2 = 1, FIN_SUM_OVER_N = 2 };
 // FIN_STATS: out[n][c] = (mean, rstd) from (sum, sumsq);  FIN_MEAN2: out[n][c] = (s0/V, s1/V);
 // FIN_SUM_OVER_N: out[a][c] = sum over n and chunks (NACC planes)
-// one 64-lane wave per output element: lanes stride over the chunks, xor-shuffle combine (fp64)
-__global__ __launch_bounds__(256) void colreduce_finalize(const float* __restrict__ partial, int N, int nchunks, int nacc, int C, double V,
-                                                          float eps, int mode, float* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // element index (wave-uniform)
-  if (mode == FIN_SUM_OVER_N) {
-    if (i >= nacc * C) return;
-    int a = i / C, c = i - a * C;
-    double s = 0.0;
-    for (int k = lane; k < N * nchunks; k += 64) s += (double)partial[((size_t)k * nacc + a) * C + c];
-    s = wave_sum_d(s);
-    if (lane == 0) out[i] = (float)s;
-    return;
+// one WORKGROUP per output element: the 256 threads stride over the chunks with up to four independent loads each in flight
+// (a wave per element walked 512 chunks in 8 dependent round trips: 6.4 us per launch on average, 30 at worst, 71 launches per
+// cfg2 step, every one of them between two kernels that depend on it), fp64 xor-shuffle combine, the four waves added in order.
+__device__ inline void fin_gather(const float* __restrict__ base, size_t row_stride, int rows, int second, double& s0, double& s1) {
+  const int tid = threadIdx.x;
+  for (int k0 = tid; k0 < rows; k0 += 1024) {
+    float v0[4], v1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + 256 * u;
+      const bool ok = k < rows;
+      const float* p = base + (size_t)(ok ? k : 0) * row_stride;
+      v0[u] = ok ? p[0] : 0.f;
+      v1[u] = (ok && second) ? p[second] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s0 += (double)v0[u], s1 += (double)v1[u];
   }
-  if (i >= N * C) return;
-  int n = i / C, c = i - n * C;
-  double s0 = 0.0, s1 = 0.0;
-  for (int k = lane; k < nchunks; k += 64) {
-    const float* p = partial + ((size_t)(n * nchunks + k) * 2) * C + c;
-    s0 += (double)p[0];
-    s1 += (double)p[C];
-  }
+  __shared__ double red[2][4];
   s0 = wave_sum_d(s0);
   s1 = wave_sum_d(s1);
-  if (lane != 0) return;
+  if ((tid & 63) == 0) red[0][tid >> 6] = s0, red[1][tid >> 6] = s1;
+  __syncthreads();
+  s0 = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+  s1 = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+}
+__global__ __launch_bounds__(256) void colreduce_finalize(const float* __restrict__ partial, int N, int nchunks, int nacc, int C, double V,
+                                                          float eps, int mode, float* __restrict__ out) {
+  const int i = blockIdx.x;  // element index
+  double s0 = 0.0, s1 = 0.0;
+  if (mode == FIN_SUM_OVER_N) {
+    const int a = i / C, c = i - a * C;
+    fin_gather(partial + (size_t)a * C + c, (size_t)nacc * C, N * nchunks, 0, s0, s1);
+    if (threadIdx.x == 0) out[i] = (float)s0;
+    return;
+  }
+  const int n = i / C, c = i - n * C;
+  fin_gather(partial + ((size_t)n * nchunks * 2) * C + c, (size_t)2 * C, nchunks, C, s0, s1);
+  if (threadIdx.x != 0) return;
   if (mode == FIN_STATS) {
     double mean = s0 / V;
     double var = s1 / V - mean * mean;
@@ -165,6 +179,12 @@ __global__ __launch_bounds__(256) void colreduce_finalize(const float* __restric
     out[2 * i] = (float)(s0 / V);
     out[2 * i + 1] = (float)(s1 / V);
   }
+}
+
+static inline void fin_launch(hipStream_t st, const float* partial, int N, int nchunks, int nacc, int C, double V, float eps, int mode,
+                              float* out) {
+  const int elems = mode == FIN_SUM_OVER_N ? nacc * C : N * C;
+  hipLaunchKernelGGL(colreduce_finalize, dim3(elems), dim3(256), 0, st, partial, N, nchunks, nacc, C, V, eps, mode, out);
 }
 
 template <typename T>
@@ -230,7 +250,7 @@ extern "C" int rx_instnorm_stats(rx_dtype dt, const rx_act* y, float eps, float*
     hipLaunchKernelGGL((colreduce_kernel<T, 2, StatsOp<T>>), dim3(p.nchunks, y->n), dim3(256), lds, st, op, (int)V, y->c,
                        p.chunk_vox, (float*)ws);
     int tot = y->n * y->c;
-    hipLaunchKernelGGL(colreduce_finalize, dim3((tot + 3) / 4), dim3(256), 0, st, (const float*)ws, y->n, p.nchunks, 2,
+    fin_launch(st, (const float*)ws, y->n, p.nchunks, 2,
                        y->c, (double)V, eps, (int)FIN_STATS, stats);
   });
   RX_CHECK_LAUNCH("rx_instnorm_stats");
@@ -260,7 +280,7 @@ extern "C" int rx_instnorm_stats_mask(float* stats, const float* keep, int count
 // (mean, rstd) from per-chunk partial sums laid out like colreduce_kernel's (rx_conv_halo.hip leaves such partials behind
 // when a persistent conv kernel accumulates the statistics of its own output)
 void rx_stats_finalize_launch(const float* partial, int N, int nchunks, int C, double V, float eps, float* stats, hipStream_t st) {
-  hipLaunchKernelGGL(colreduce_finalize, dim3((N * C + 3) / 4), dim3(256), 0, st, partial, N, nchunks, 2, C, V, eps, (int)FIN_STATS, stats);
+  fin_launch(st, partial, N, nchunks, 2, C, V, eps, (int)FIN_STATS, stats);
 }
 
 // ---- per-channel sum over (n, voxels) -------------------------------------------------------
@@ -294,7 +314,7 @@ extern "C" int rx_channel_sum(rx_dtype dt, const rx_act* x, float* out, void* ws
     size_t lds = (size_t)(VP > 4 ? VP : 4) * x->c * sizeof(float);
     hipLaunchKernelGGL((colreduce_kernel<T, 1, SumOp<T>>), dim3(p.nchunks, x->n), dim3(256), lds, st, op, (int)V, x->c,
                        p.chunk_vox, (float*)ws);
-    hipLaunchKernelGGL(colreduce_finalize, dim3((x->c + 3) / 4), dim3(256), 0, st, (const float*)ws, x->n, p.nchunks, 1,
+    fin_launch(st, (const float*)ws, x->n, p.nchunks, 1,
                        x->c, (double)V, 0.f, (int)FIN_SUM_OVER_N, out);
   });
   RX_CHECK_LAUNCH("rx_channel_sum");
@@ -712,7 +732,7 @@ extern "C" int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y
     size_t lds = (size_t)2 * (VP > 4 ? VP : 4) * C * sizeof(float);
     hipLaunchKernelGGL((colreduce_kernel<T, 2, InBwdOp<T>>), dim3(p.nchunks, N), dim3(256), lds, st, op, (int)V, C, p.chunk_vox,
                        partial);
-    hipLaunchKernelGGL(colreduce_finalize, dim3((N * C + 3) / 4), dim3(256), 0, st, (const float*)partial, N, p.nchunks, 2, C,
+    fin_launch(st, (const float*)partial, N, p.nchunks, 2, C,
                        (double)V, 0.f, (int)FIN_MEAN2, m12);
     int G = sweep_grid(V * CV, CV);
     const T* outp = use_mask ? (const T*)out->ptr : nullptr;
@@ -1218,7 +1238,7 @@ extern "C" int rx_head_bwd(rx_dtype dt, const float* dout_ncdhw, const rx_act* x
         hipLaunchKernelGGL((head_bwd_kernel<T, 16>), dim3(p.nchunks, N), dim3(256), lds, st, dout_ncdhw, (const T*)x->ptr, x->ld, V * x->ld, w, kc,
                            k0, k, dxp, dx ? dx->ld : 0, dx ? V * dx->ld : 0L, (int)V, C, p.chunk_vox, partial);
       }
-      hipLaunchKernelGGL(colreduce_finalize, dim3(((kc + 1) * C + 3) / 4), dim3(256), 0, st, (const float*)partial, N, p.nchunks, kc + 1,
+      fin_launch(st, (const float*)partial, N, p.nchunks, kc + 1,
                          C, (double)V, 0.f, (int)FIN_SUM_OVER_N, fin);
       (void)hipMemcpyAsync(dw + (size_t)k0 * C, fin, (size_t)kc * C * sizeof(float), hipMemcpyDeviceToDevice, st);
       (void)hipMemcpyAsync(db + k0, fin + (size_t)kc * C, (size_t)kc * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -1470,7 +1490,7 @@ extern "C" int rx_instnorm_act_bwd_head(rx_dtype dt, const float* dout_ncdhw, in
     size_t lds = (size_t)2 * (VP > 4 ? VP : 4) * C * sizeof(float);
     hipLaunchKernelGGL((colreduce_kernel<T, 2, InBwdHeadOp<T>>), dim3(p.nchunks, N), dim3(256), lds, st, op, (int)V, C, p.chunk_vox,
                        partial);
-    hipLaunchKernelGGL(colreduce_finalize, dim3((N * C + 3) / 4), dim3(256), 0, st, (const float*)partial, N, p.nchunks, 2, C,
+    fin_launch(st, (const float*)partial, N, p.nchunks, 2, C,
                        (double)V, 0.f, (int)FIN_MEAN2, m12);
     int G = sweep_grid(V * CV, CV);
     hipLaunchKernelGGL((in_act_bwd_apply_head_kernel<T>), dim3(G, N), dim3(256), 0, st, dout_ncdhw, k, head_w, (const T*)y->ptr, y->ld,
