@@ -4,7 +4,9 @@
 `SyntheticPatchDataset` generates SURVEY 8(d)'s synthetic patches (what the headline metric is quoted on).
 `ZarrSegmentationDataset3D` reads real zarr v2 volumes through `zarr_lite` (the `zarr` package is absent here): same
 constructor, valid-patch search, cache file, dtype scaling and item layout as the reference; its augmentations need
-albumentations / volumentations (absent) and are NOT applied, remote (http) stores are refused (no network)."""
+albumentations / volumentations (absent): `dataloading/augment.py` restates the stack in numpy (parity unpinned) and is applied
+by default with ONE warning saying so (`dataset_config.augment: "restated"` acknowledges it, `false` feeds raw patches); remote
+(http) stores are refused (no network)."""
 import json
 import os
 import warnings
@@ -103,7 +105,7 @@ def _ball(radius):
 
 
 class ZarrSegmentationDataset3D(Dataset):
-    """dataloading/dataset.py:18-222 without the augmentation stack (see the module docstring)."""
+    """dataloading/dataset.py:18-222; the augmentation stack (:171-205) through `augment.py` (see the module docstring)."""
     _warned = False
 
     def __init__(self, mgr):
@@ -118,14 +120,20 @@ class ZarrSegmentationDataset3D(Dataset):
         self.use_cache = mgr.use_cache
         self.cache_folder = mgr.cache_folder
         # the reference's recipe augments every item (dataset.py:171-205: brightness / noise / blur OneOf groups,
-        # CoarseDropout3D) with albumentations / volumentations, which are not installed here: say so ONCE per process instead
-        # of silently training a different recipe; `dataset_config.augment: false` acknowledges it
-        if bool(getattr(mgr, "dataset_config", {}).get("augment", True)) and not ZarrSegmentationDataset3D._warned:
+        # CoarseDropout3D) with albumentations / volumentations, which are not installed here.  `augment.py` restates that
+        # stack; say ONCE per process that it is a restatement instead of silently training a slightly different recipe.
+        # dataset_config.augment: true (default) = restated stack + the warning, "restated" = acknowledged, false = raw patches
+        mode = getattr(mgr, "dataset_config", {}).get("augment", True)
+        if isinstance(mode, str) and mode.lower() not in ("restated", "true", "false"):
+            raise ValueError(f"dataset_config.augment: {mode!r} (true, false or \"restated\")")
+        self.augment = (mode.lower() != "false") if isinstance(mode, str) else bool(mode)
+        if self.augment and not (isinstance(mode, str) and mode.lower() == "restated") and not ZarrSegmentationDataset3D._warned:
             ZarrSegmentationDataset3D._warned = True
             warnings.warn("ZarrSegmentationDataset3D: the reference's augmentation stack (dataloading/dataset.py:171-205) needs "
-                          "albumentations / volumentations, which are absent -- patches are fed UN-AUGMENTED, so a real-data "
-                          "run is not the reference's training recipe.  Set dataset_config.augment: false to acknowledge.",
-                          RuntimeWarning, stacklevel=2)
+                          "albumentations / volumentations, which are absent -- patches go through the numpy RESTATEMENT of it "
+                          "(dataloading/augment.py: same structure and probabilities, the members' default parameters as "
+                          "documented; not compared with albumentations).  Set dataset_config.augment: \"restated\" to "
+                          "acknowledge, or false to feed raw patches.", RuntimeWarning, stacklevel=2)
         self.volumes = []
         for vol_idx, info in enumerate(self.volume_paths):
             vd = {"input_path": info["input"], "targets_path": {}, "ref_label_key": info.get("ref_label", "sheet")}
@@ -189,6 +197,9 @@ class ZarrSegmentationDataset3D(Dataset):
                     from scipy.ndimage import binary_dilation      # == skimage dilation(t > 0, ball(5)) on a 0/1 volume
                     t = binary_dilation(t > 0, structure=_ball(5)).astype(np.float32)
             item[task] = t
+        if self.augment:              # image only; targets untouched (dataset.py:200-205)
+            from .augment import augment_image
+            item["image"] = augment_image(item["image"])
         if item["image"].ndim == 3:
             item["image"] = item["image"][None, ...]
         item["image"] = torch.from_numpy(np.ascontiguousarray(item["image"]))

@@ -96,6 +96,7 @@ def test_training_from_zarr_volumes_with_squeeze_excite(tmp_path):
     cfg["model_config"] = {"conv_bias": False, "squeeze_excitation": True}
     cfg["dataset_config"].update(synthetic=False, min_labeled_ratio=0.05, min_bbox_percent=0.5, use_cache=True,
                                  cache_folder=str(tmp_path / "cache"),
+                                 augment=False,       # 24 steps must show learning: raw patches (the stack: tests/test_augment.py)
                                  volume_paths=[{"input": str(tmp_path / "img.zarr"), "sheet": str(tmp_path / "sheet.zarr"),
                                                 "ref_label": "sheet"}])
     p = tmp_path / "cfg.yaml"

@@ -73,15 +73,19 @@ def test_dataset_items_and_valid_patches(tmp_path):
                           volume_paths=[{"input": paths["img"], "sheet": paths["sheet"], "normals": paths["normals"],
                                          "ref_label": "sheet"}])
     ZarrSegmentationDataset3D._warned = False
-    with pytest.warns(RuntimeWarning, match="UN-AUGMENTED"):        # the missing augmentation stack is announced, once
-        ds = ZarrSegmentationDataset3D(mgr)
+    with pytest.warns(RuntimeWarning, match="RESTATEMENT"):         # the restated augmentation stack is announced, once
+        aug = ZarrSegmentationDataset3D(mgr)
+    assert aug.augment
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         ZarrSegmentationDataset3D(mgr)                              # second construction: silent
         ZarrSegmentationDataset3D._warned = False
-        mgr.dataset_config = {"augment": False}                     # acknowledged in the config: silent
-        ZarrSegmentationDataset3D(mgr)
+        mgr.dataset_config = {"augment": "restated"}                # acknowledged in the config: silent
+        assert ZarrSegmentationDataset3D(mgr).augment
+        mgr.dataset_config = {"augment": False}                     # raw patches: silent
+        ds = ZarrSegmentationDataset3D(mgr)
+        assert not ds.augment
     nz = np.argwhere(lab > 0)
     bbox = tuple(int(v) for ax in range(3) for v in (nz[:, ax].min(), nz[:, ax].max()))
     assert find_label_bounding_box(zarr_lite.open(paths["sheet"]), (16, 16, 16)) == bbox
