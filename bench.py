@@ -281,6 +281,9 @@ def main():
                     help="also run the workload through the plug-in surface (BaseTrainer + SyntheticPatchDataset + DataLoader) "
                          "and report its patches/s as `trainer`")
     ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)   # "gloo": rehearse N>1 on a 1-GPU box
+    ap.add_argument("--bucket-mb", type=float, default=128.0,
+                    help="gradient bucket size of the all-reduce in MiB (N > 1; engine/ddp.py::GradSync); xGMI is point-to-point, "
+                         "so few large buckets keep RCCL in its bandwidth regime")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -334,7 +337,9 @@ def main():
     else:
         opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.0, fused=True)
     x, targets = synthetic_batch(w, batch, 1234 + rank, device)
-    sync = GradSync() if world > 1 else None
+    sync = GradSync(bucket_bytes=int(args.bucket_mb * (1 << 20))) if world > 1 else None
+    if sync is not None:
+        sync.timing = True          # two event records per backward around finish()'s waits: the exposed tail of the overlap
     # RX_STREAMED_STEP=1: the optimizer update + weight re-pack on the engine's side stream in forward order, overlapped
     # with the next forward (bit-identical parameters).  Off by default: the GPU is throughput-saturated, hiding the
     # HBM-bound update under the forward measured 23.7 vs 23.5 ms per step
@@ -382,6 +387,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    ddp_block = None
+    if sync is not None:
+        # self-describing multi-GPU run: what the collectives were, and how much of them the backward did NOT hide
+        tails = sync.tail_ms()[-args.steps:]
+        ddp_block = dict(sync.describe(), world_env=world, bucket_mb=args.bucket_mb,
+                         backend_is_rccl=bool(args.dist_backend == "nccl" and torch.version.hip),
+                         exposed_tail_ms=dict(mean=sum(tails) / max(len(tails), 1), max=max(tails) if tails else None, steps=len(tails)),
+                         note="exposed tail = device time between the last backward kernel on the main stream and the moment every "
+                              "bucket's all-reduce has landed (GradSync.finish); buckets are launched from inside the backward, in "
+                              "gradient-readiness order, on a side HIP stream")
+        sync.timing = False
     # ---- the same K steps with the H2D copy of image + targets INSIDE the step (the reference's step starts at
     # the `.to(device)` of a pinned DataLoader batch, train.py:195-201): two pinned host batches, two device batches, a copy
     # stream that brings batch i+1 while step i computes.  Reported beside `value` (which keeps the batch resident in HBM),
@@ -530,6 +546,7 @@ def main():
             "kernels": kernels,
             "hbm": hbm,
             "with_h2d": h2d,
+            "ddp": ddp_block,
         }
         if iso is not None:
             gi = iso.collect()

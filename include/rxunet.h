@@ -14,6 +14,9 @@
  *  - parameters and parameter gradients cross the boundary in PyTorch's own layouts
  *    (Conv3d (Co,Ci,kz,ky,kx), ConvTranspose3d (Ci,Co,kz,ky,kx)), fp32.
  *
+ * Environment knobs (RX_*, listed in README.md) are measurement switches: the library reads each ONCE per thread, at the first
+ * call that consults it, and keeps the answer -- changing one inside a running process has no effect.
+ *
  * Each entry point names the torch primitive of the reference it replaces (file:line relative to
  * /root/reference).  The Python binding a maintainer would add is in INTEGRATION.md.
  */
@@ -286,6 +289,10 @@ int rx_prog_run(rx_prog* p, int first, int last, void* const* streams, int n_str
 /* numbered events for cross-stream ordering (recordable like everything else): rx_stream_wait makes `stream` wait for the
  * work captured by the last rx_event_record(slot) issued before it. */
 int rx_event_new(void);
+/* return a slot to the library (a plan frees its slots when it is destroyed; programs that mention the slot must be destroyed
+ * first).  rx_event_slots_in_use: how many slots are handed out right now (leak checks). */
+int rx_event_free(int slot);
+int rx_event_slots_in_use(void);
 int rx_event_record(int slot, void* stream);
 int rx_stream_wait(int slot, void* stream);
 

@@ -192,6 +192,8 @@ class NetworkFromConfig(nn.Module):
         return plan
 
     def _apply(self, fn, *a, **k):   # .to()/.cuda()/.float() move parameters: cached plans hold stale pointers
+        for plan in self._plans.values():     # (plans are reference cycles of closures: hand their library resources back now)
+            plan.release()
         self._plans = {}
         return super()._apply(fn, *a, **k)
 

@@ -15,8 +15,11 @@
 #define RX_NO_HOST_MACROS 1
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
+#include <utility>
 
 #include "rx_common.h"
 #include "rx_prog.h"
@@ -137,17 +140,47 @@ extern "C" int rx_prog_run(rx_prog* p, int first, int last, void* const* streams
 }
 
 // ---- numbered events: cross-stream ordering that can be recorded -----------------------------------------------------
-#define RX_MAX_EVENTS 65536      // slots are never recycled: ~60 per plan (events are created on first use)
+// ~60 slots per plan (events are created on first use).  A plan returns its slots with rx_event_free when it is destroyed (a
+// long-lived process that rebuilds plans -- `.to()`, many input shapes in inference -- used to run out); the table is
+// guarded by a mutex because ctypes releases the GIL and the backward pass runs on autograd's thread.
+#define RX_MAX_EVENTS 65536
 static hipEvent_t g_events[RX_MAX_EVENTS];
 static bool g_event_made[RX_MAX_EVENTS];
+static bool g_event_live[RX_MAX_EVENTS];
 static int g_event_next = 0;
+static std::vector<int> g_event_freelist;
+static std::mutex g_event_mu;
 
 extern "C" int rx_event_new(void) {
-  if (g_event_next >= RX_MAX_EVENTS) RX_FAIL(RX_EINVAL, "rx_event_new: out of event slots");
-  return g_event_next++;
+  std::lock_guard<std::mutex> lock(g_event_mu);
+  int slot;
+  if (!g_event_freelist.empty()) {
+    slot = g_event_freelist.back();
+    g_event_freelist.pop_back();
+  } else {
+    if (g_event_next >= RX_MAX_EVENTS) RX_FAIL(RX_EINVAL, "rx_event_new: out of event slots");
+    slot = g_event_next++;
+  }
+  g_event_live[slot] = true;
+  return slot;
+}
+// give a slot back (its hipEvent_t, if one was created, is kept and re-used by the next owner: a wait on a recycled event that
+// was last recorded by the previous owner waits for work that is long complete or, at worst, for work of the same device).
+// The caller must not use the number afterwards; recorded programs that mention it must be destroyed first.
+extern "C" int rx_event_free(int slot) {
+  std::lock_guard<std::mutex> lock(g_event_mu);
+  if (slot < 0 || slot >= g_event_next || !g_event_live[slot]) RX_FAIL(RX_EINVAL, "rx_event_free: slot %d is not in use", slot);
+  g_event_live[slot] = false;
+  g_event_freelist.push_back(slot);
+  return RX_OK;
+}
+extern "C" int rx_event_slots_in_use(void) {
+  std::lock_guard<std::mutex> lock(g_event_mu);
+  return g_event_next - (int)g_event_freelist.size();
 }
 static hipEvent_t* event_slot(int slot) {
-  if (slot < 0 || slot >= g_event_next) return nullptr;
+  std::lock_guard<std::mutex> lock(g_event_mu);
+  if (slot < 0 || slot >= g_event_next || !g_event_live[slot]) return nullptr;
   if (!g_event_made[slot]) {
     // These events only order streams of ONE device (producer kernel -> consumer kernel; every kernel still ends with its own
     // device-scope release), nobody synchronises the HOST on them: created without the system-scope fence (no cache write-back /
@@ -187,11 +220,16 @@ const char* rx_getenv_cached(const char* name) {
   return v;
 }
 hipError_t rx_func_attr_once(const void* fn, hipFuncAttribute attr, int value) {
-  static thread_local std::unordered_map<const void*, int> done;               // largest value already set per kernel
+  // largest value already set per (device, kernel): the attribute belongs to the kernel's code object ON ONE DEVICE, so a
+  // second device of the same process must get its own call
+  static thread_local std::map<std::pair<int, const void*>, int> done;
   if (attr != hipFuncAttributeMaxDynamicSharedMemorySize) return hipFuncSetAttribute(fn, attr, value);
-  auto it = done.find(fn);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const auto key = std::make_pair(dev, fn);
+  auto it = done.find(key);
   if (it != done.end() && it->second >= value) return hipSuccess;
   const hipError_t e = hipFuncSetAttribute(fn, attr, value);
-  if (e == hipSuccess) done[fn] = value;
+  if (e == hipSuccess) done[key] = value;
   return e;
 }

@@ -22,7 +22,9 @@ from . import zarr_lite
 class SyntheticPatchDataset(Dataset):
     """SURVEY 8(d)'s synthetic patches.  `dataset_config.synthetic_pool` (default 16) distinct patches are generated once per
     process and handed out round-robin: drawing 2 x 128^3 uniform numbers per item costs ~60 ms of one CPU core, which would make
-    a 128^3 training run loader-bound at ~8 patches/s; 0 = draw every item afresh."""
+    a 128^3 training run loader-bound at ~8 patches/s; 0 = draw every item afresh.  With a pool the trainer's train / validation
+    split (train.py:99-120 mirror) hands out the SAME pool to both sides: synthetic validation numbers measure throughput and
+    plumbing, not generalisation (set `synthetic_pool: 0` for disjoint samples)."""
 
     def __init__(self, mgr, length=None, seed=1234):
         self.mgr = mgr

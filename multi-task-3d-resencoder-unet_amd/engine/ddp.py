@@ -22,6 +22,7 @@ The reference has no multi-GPU path; this is a new-build requiremen
 Works unchanged with the gloo backend on CPU tensors (used by the world_size-2 tests).
 """
 import contextlib
+import weakref
 from typing import Dict, List, Optional
 
 import torch
@@ -29,14 +30,14 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("idxs", "offsets", "numel", "flat", "pflat", "pending", "work", "streams", "carry")
+    __slots__ = ("idxs", "offsets", "numel", "flat", "pflat", "pending", "work", "streams", "t_closed")
 
     def __init__(self):
         self.idxs, self.offsets, self.numel = [], {}, 0
         self.flat, self.pending, self.work = None, 0, None
         self.pflat = None          # the bucket's PERSISTENT storage (a plan that replays a recorded backward writes fixed addresses)
         self.streams = {}          # stream id -> torch.cuda.Stream of every producer of this bucket (this backward)
-        self.carry = None          # local sum of the un-synchronised micro-batches (gradient accumulation)
+        self.t_closed = None       # (optional, GradSync.timing) event recorded on the collective's stream behind the collective
 
 
 class GradSync:
@@ -50,7 +51,13 @@ class GradSync:
         # RCCL averages inside the collective (ncclAvg; probed on this image with scripts/nccl_avg_probe.py): no
         # pre-scale pass over the 853 MB of gradients.  gloo has no AVG -> pre-scale by 1/world there.
         self._native_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
-        self._layout: Dict[int, List[_Bucket]] = {}
+        # static bucket layout per plan, keyed by the plan OBJECT (weakly: `id(plan)` can be recycled once a model drops its
+        # plans in `_apply`)
+        self._layout: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+        # Gradient-accumulation carry, keyed by the PARAMETER (not by plan or bucket): within one accumulation window the
+        # micro-batches may run on different plans of one model (a ragged last batch of an epoch has another batch size), and
+        # the stepping micro-batch must reduce every carried gradient whatever plan produced it.
+        self._carry: Dict[torch.nn.Parameter, torch.Tensor] = {}
         self._cur: Optional[List[_Bucket]] = None
         self._of: Dict[int, _Bucket] = {}
         self._params = None
@@ -59,6 +66,29 @@ class GradSync:
         self.require_sync = True        # False: accumulate locally, no collective (see no_sync)
         self._syncing = True            # value of require_sync latched by begin() for the running backward
         self.stats = dict(buckets=0, bytes=0, collectives=0)
+        # timing = True: every finish() brackets its waits (collectives still in flight when the backward's last kernel is
+        # enqueued = the EXPOSED tail of the overlap) with events on the current stream; tail_ms() reads them (bench.py's `ddp` block)
+        self.timing = False
+        self._tails: List[tuple] = []
+
+    def describe(self):
+        """what the bench line's `ddp` block reports about this synchroniser (static facts + the last backward's counters)"""
+        backend = dist.get_backend(self.group) if dist.is_initialized() else None
+        return dict(backend=backend, world=self.world, bucket_bytes=self.bucket_bytes, tail_bytes=self.tail_bytes,
+                    reduce_op=("avg" if (self.average and self._native_avg) else ("sum/world" if self.average else "sum")),
+                    buckets=self.stats["buckets"], bytes=self.stats["bytes"], collectives=self.stats["collectives"])
+
+    def tail_ms(self):
+        """exposed tail of every timed backward so far (ms), oldest first; clears the list"""
+        out = []
+        for a, b in self._tails:
+            if isinstance(a, float):
+                out.append((b - a) * 1e3)
+            else:
+                b.synchronize()
+                out.append(a.elapsed_time(b))
+        self._tails = []
+        return out
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -77,7 +107,7 @@ class GradSync:
 
     # ---- static layout per plan -----------------------------------------------------------------
     def _plan_layout(self, plan):
-        key = id(plan)
+        key = plan
         if key in self._layout:
             return self._layout[key]
         buckets, cur = [], _Bucket()
@@ -139,11 +169,13 @@ class GradSync:
             self._side = torch.cuda.Stream(device=dev)
         self.stats = dict(buckets=len(self._cur), bytes=sum(b.numel for b in self._cur) * 4, collectives=0)
 
-    def alloc(self, idx):
-        b = self._of[idx]
+    def _view(self, b, idx):
         p = self._params[idx]
         o = b.offsets[idx]
         return b.flat[o:o + p.numel()].view(p.shape)
+
+    def alloc(self, idx):
+        return self._view(self._of[idx], idx)
 
     def ready(self, idx):
         """called right after the LAST kernel writing gradient `idx` was enqueued, on the stream it was enqueued on"""
@@ -157,12 +189,19 @@ class GradSync:
 
     def _reduce(self, b):
         """(on the collective's stream / the host for CPU tensors) carry + own gradients, then the collective"""
-        if b.carry is not None:
-            b.flat.add_(b.carry)
-            b.carry = None
+        views = [self._view(b, i) for i in b.idxs]
+        held = [(v, self._carry.pop(self._params[i], None)) for v, i in zip(views, b.idxs)]
+        held = [(v, c) for v, c in held if c is not None]
+        if held:
+            torch._foreach_add_([v for v, _ in held], [c for _, c in held])
         if not self._syncing:
-            # stays local; the stepping micro-batch picks it up (a copy when the bucket storage is reused by the next backward)
-            b.carry = b.flat.clone() if self.persistent else b.flat
+            # stays local; the stepping micro-batch picks it up -- on whatever plan it runs (a copy when the bucket storage is
+            # reused by the next backward)
+            keep = b.flat.clone() if self.persistent else b.flat
+            for i in b.idxs:
+                p = self._params[i]
+                o = b.offsets[i]
+                self._carry[p] = keep[o:o + p.numel()].view(p.shape)
             return
         if self.world == 1 and not self.force_collectives:
             return
@@ -175,7 +214,8 @@ class GradSync:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _launch(self, b):
-        if self.world == 1 and b.carry is None and self._syncing and not self.force_collectives:
+        if (self.world == 1 and self._syncing and not self.force_collectives
+                and not any(self._params[i] in self._carry for i in b.idxs)):
             return
         if b.flat.is_cuda:
             # every stream that produced into this bucket: the kernels enqueued there so far include all of the bucket's
@@ -190,20 +230,35 @@ class GradSync:
             self._reduce(b)
 
     def finish(self):
+        cuda = bool(self._cur) and self._cur[0].flat.is_cuda
+        t0 = None
+        if self.timing:
+            if cuda:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record()
+            else:
+                import time
+                t0 = time.perf_counter()
         for b in self._cur or []:
             if b.pending != 0:
                 raise RuntimeError("gradient bucket not completed: a parameter of the plan produced no gradient")
             if b.work is not None:
                 b.work.wait()                          # makes the CURRENT stream wait for the collective
-        if self._cur and self._cur[0].flat.is_cuda and self._side is not None:
+        if cuda and self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
+        if t0 is not None:
+            if cuda:
+                t1 = torch.cuda.Event(enable_timing=True)
+                t1.record()
+            else:
+                import time
+                t1 = time.perf_counter()
+            self._tails.append((t0, t1))
         self._cur = None
 
     def drop_carry(self):
         """forget accumulated local gradients (e.g. `optimizer.zero_grad()` in the middle of an accumulation window)"""
-        for buckets in self._layout.values():
-            for b in buckets:
-                b.carry = None
+        self._carry.clear()
 
 
 def broadcast_parameters(module, src=0, group=None):

@@ -111,6 +111,8 @@ _SIGNATURES = {
     "rx_prog_cmd_stream": (c_int, [c_void_p, c_int]),
     "rx_prog_run": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "rx_event_new": (c_int, []),
+    "rx_event_free": (c_int, [c_int]),
+    "rx_event_slots_in_use": (c_int, []),
     "rx_event_record": (c_int, [c_int, c_void_p]),
     "rx_stream_wait": (c_int, [c_int, c_void_p]),
     "rx_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_double, c_int,

@@ -80,6 +80,11 @@ def event_new():
     return int(load().rx_event_new())
 
 
+def event_free(slot):
+    """hand a numbered event back to the library (programs that mention it must be gone first)"""
+    check(load().rx_event_free(int(slot)), "rx_event_free")
+
+
 def _sp(stream):
     return stream_ptr() if stream is None else c_void_p(stream.cuda_stream)
 

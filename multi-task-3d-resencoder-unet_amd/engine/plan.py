@@ -181,6 +181,28 @@ class Plan:
         self._dl_static: Dict[str, torch.Tensor] = {}
         self._build()
 
+    def release(self):
+        """drop the recorded programs and return this plan's numbered events to the library (65536 slots per process; a model that
+        rebuilds plans -- `.to()`, many input shapes in inference -- used to leak ~60 per plan).  Idempotent; called
+        by `__del__` and by the model when it discards its plans."""
+        try:
+            self._pstate.clear()                  # programs first: they mention the slots
+            slots = set(self._dy_ev.values()) | set(self._pack_slots)
+            for s in (self._ev_fork, self._ev_join):
+                if s is not None:
+                    slots.add(s)
+            self._dy_ev, self._pack_slots, self._ev_fork, self._ev_join = {}, [], None, None
+            self._dy_free = {}
+            for ent in self.packs:
+                ent["event"] = None
+            for s in slots:
+                ops.event_free(s)
+        except Exception:       # interpreter shutdown: the library may be gone
+            pass
+
+    def __del__(self):
+        self.release()
+
     # ------------------------------------------------------------------ helpers
     def _k3(self, v):
         v = list(v)
@@ -742,7 +764,11 @@ class Plan:
             P._grads[idx] = g
             return g
 
-        skip = set(filter(None, os.environ.get("RX_SKIP", "").split(",")))     # TIMING ABLATIONS ONLY (wrong results)
+        # TIMING ABLATIONS ONLY (wrong results): honoured only together with RX_ABLATION=1, anything else is an error
+        skip = set(filter(None, os.environ.get("RX_SKIP", "").split(",")))
+        if skip and os.environ.get("RX_ABLATION", "0") != "1":
+            raise _l.RxError("RX_SKIP drops launches from the backward pass (timing ablations, wrong gradients): "
+                             "set RX_ABLATION=1 as well to confirm, or unset RX_SKIP")
 
         def done(idx):
             if idx in P._pad_idx:               # completed (and announced to a gradient synchroniser) in _backward_finish

@@ -90,3 +90,25 @@ def test_header_is_plain_c_and_a_c_host_links_against_the_library(tmp_path):
     assert lines[1] == "0"                                  # a bad descriptor: size 0, no crash
     rc, msg = lines[2].split(" ", 1)
     assert int(rc) < 0 and "rx_instnorm_stats_mask" in msg  # status + message, as every entry point
+
+
+def test_numbered_event_slots_are_recycled():
+    """slots were never returned, so a process that keeps rebuilding plans ran into `out of event slots`.  The table
+    is host state only (a hipEvent_t is created at the first record), so this runs without a device."""
+    import mt3d_amd  # noqa: F401
+    from mt3d_amd.engine import lib
+    so = lib.load()
+    base = so.rx_event_slots_in_use()
+    a = [so.rx_event_new() for _ in range(8)]
+    assert len(set(a)) == 8 and so.rx_event_slots_in_use() == base + 8
+    for s in a[:5]:
+        assert so.rx_event_free(s) == 0
+    assert so.rx_event_slots_in_use() == base + 3
+    assert so.rx_event_free(a[0]) != 0 and b"not in use" in so.rx_last_error()      # double free is refused
+    b = [so.rx_event_new() for _ in range(5)]
+    assert sorted(b) == sorted(a[:5])                                                 # the freed numbers come back
+    for s in a[5:] + b:
+        assert so.rx_event_free(s) == 0
+    assert so.rx_event_slots_in_use() == base
+    for _ in range(70000):                                                            # more than the table holds, with recycling
+        assert so.rx_event_free(so.rx_event_new()) == 0

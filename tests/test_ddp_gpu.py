@@ -336,3 +336,31 @@ def test_rccl_backend_rehearsal_in_a_world_of_one():
     assert "error" not in info, info
     assert info["backend"] == "nccl" and info["stats"]["buckets"] >= 2 and info["stats"]["collectives"] == info["stats"]["buckets"], info
     assert ok, info
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_emits_a_populated_ddp_block():
+    """`bench.py --gpus 2` (launched exactly as the driver launches it, two ranks sharing cuda:0, gloo instead of
+    RCCL because one GPU cannot host an RCCL world of two) prints a bench line whose `ddp` block describes the collectives:
+    backend, world as the process group sees it, buckets, bytes, one collective per bucket, the exposed tail."""
+    import json
+    import subprocess
+    port = 35500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3",
+           "--workload", "cfg1", "--dist-backend", "gloo", "--bucket-mb", "32", "--no-cpu-baseline", "--no-kernel-timing",
+           "--no-h2d", "--no-pmc"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    d = line["ddp"]
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 4
+    assert d["backend"] == "gloo" and d["world"] == 2 and d["world_env"] == 2 and d["backend_is_rccl"] is False
+    assert d["bucket_mb"] == 32 and d["bucket_bytes"] == 32 << 20
+    assert d["buckets"] >= 2 and d["collectives"] == d["buckets"], d
+    assert d["bytes"] >= 4 * 112_000_000, d          # the 64^3 network's 112 M parameters, fp32
+    assert d["exposed_tail_ms"]["steps"] == 3 and d["exposed_tail_ms"]["mean"] >= 0.0
+    assert line["value"] > 0
