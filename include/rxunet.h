@@ -141,6 +141,16 @@ int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y, const flo
                         float slope, const rx_act* dy, const rx_act* d_residual, int accumulate_residual,
                         void* ws, size_t ws_bytes, void* stream);
 
+/* rx_instnorm_act_bwd for a residual-block epilogue out = lrelu(IN(y) + res) (resblocks.py:113-114) with the masked gradient
+ * g' = g * lrelu'(out) written ONCE: the reduce pass stores g' into d_residual (it IS the residual's gradient; the buffer must
+ * not hold earlier contributions -- d_residual == g is allowed) while it sums, the apply pass reads (g', y) only: 7 tensor
+ * passes instead of 8.  pool_dy / pool_stride (optional): gradient of the AvgPool that opens the next stage's skip path
+ * (resblocks.py:95), added on the fly, g <- g + pool_dy[v / stride] / prod(stride) -- replaces a preceding
+ * rx_avgpool_bwd(pool_dy, g, stride, accumulate = 1).  ws as for rx_instnorm_act_bwd. */
+int rx_instnorm_act_bwd_res(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out,
+                            float slope, const rx_act* pool_dy, const int32_t pool_stride[3], const rx_act* d_residual,
+                            const rx_act* dy, void* ws, size_t ws_bytes, void* stream);
+
 /* second pass of rx_instnorm_act_bwd alone, with the two means m12[n][c] supplied by the caller */
 int rx_instnorm_act_bwd_apply(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out,
                               float slope, const float* m12, const rx_act* dy, const rx_act* d_residual,

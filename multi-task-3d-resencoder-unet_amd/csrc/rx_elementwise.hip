@@ -749,6 +749,116 @@ extern "C" int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y
 }
 
 
+// ---- residual-block epilogue backward with the MASKED gradient materialised once --------------------------------------
+// out = lrelu(IN(y) + res) (resblocks.py:113-114).  The masked gradient g' = g * lrelu'(out) is BOTH the input of the
+// InstanceNorm backward and the gradient of the residual.  rx_instnorm_act_bwd read (g, y, out) twice and wrote dy and
+// d_residual in its second pass: 3R + 3R 2W = 8 tensor passes.  Here the reduce pass writes g' into the residual-gradient
+// buffer while it accumulates sum g' / sum g'*xhat (3R 1W) and the apply pass reads only (g', y) and writes dy (2R 1W): 7
+// passes, and the apply kernel is the mask-free, residual-free instantiation.  pool_dy (optional): the gradient of the
+// AvgPool that opens the NEXT stage's skip path (resblocks.py:95) -- g is then old_g + pool_dy[v / f] / |f| formed on the fly
+// (the separate avgpool_bwd pass over the full-resolution gradient, 1R 1W, disappears as well).
+// Sums are taken of g' AS STORED (rounded to the compute type): the apply pass sees exactly the values that were summed.
+template <typename T, bool POOL>
+struct InBwdResOp {
+  ActView<T> g, y, out, pool;
+  T* gp;            // masked gradient out (= d_residual), same geometry as y
+  long gp_ss;
+  int gp_ld;
+  const float* stats;
+  int C;
+  float slope;
+  int Yi, Xi, Yo, Xo, fz, fy, fx;
+  float inv;
+  float mean[Elem<T>::PER16], rstd[Elem<T>::PER16];
+  __device__ inline void prepare(int n, int c0) {
+#pragma unroll
+    for (int j = 0; j < Elem<T>::PER16; ++j) {
+      mean[j] = stats[2 * ((size_t)n * C + c0 + j)];
+      rstd[j] = stats[2 * ((size_t)n * C + c0 + j) + 1];
+    }
+  }
+  __device__ inline void accumulate(int n, int v, int c0, float (&acc)[2][Elem<T>::PER16]) const {
+    constexpr int P = Elem<T>::PER16;
+    Vec16<T> gv = ld16(g.at(n, v, c0));
+    Vec16<T> yv = ld16(y.at(n, v, c0));
+    Vec16<T> ov = ld16(out.at(n, v, c0));
+    Vec16<T> pv;
+    if (POOL) {
+      const int xi = v % Xi, t = v / Xi;
+      const int yi = t % Yi, zi = t / Yi;
+      const int vo = ((zi / fz) * Yo + (yi / fy)) * Xo + (xi / fx);
+      pv = ld16(pool.at(n, vo, c0));
+    }
+    Vec16<T> w;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      float gg = Elem<T>::to_f(gv.v[j]);
+      if (POOL) gg += Elem<T>::to_f(pv.v[j]) * inv;
+      if (!(Elem<T>::to_f(ov.v[j]) > 0.f)) gg *= slope;
+      w.v[j] = Elem<T>::from_f(gg);
+      gg = Elem<T>::to_f(w.v[j]);
+      const float xh = (Elem<T>::to_f(yv.v[j]) - mean[j]) * rstd[j];
+      acc[0][j] += gg;
+      acc[1][j] += gg * xh;
+    }
+    st16(gp + n * gp_ss + (long)v * gp_ld + c0, w);
+  }
+};
+
+static int check_pool(const rx_act* big, const rx_act* small, const int32_t f[3], const char* who);
+
+extern "C" int rx_instnorm_act_bwd_res(rx_dtype dt, const rx_act* g, const rx_act* y, const float* stats, const rx_act* out, float slope,
+                                       const rx_act* pool_dy, const int32_t pool_stride[3], const rx_act* d_residual, const rx_act* dy,
+                                       void* ws, size_t ws_bytes, void* stream) {
+  static const int32_t one3[3] = {1, 1, 1};
+  if (!pool_stride) pool_stride = one3;
+  RX_RECORD(stream, [=, g_ = RxActV(g), y_ = RxActV(y), out_ = RxActV(out), pool_dy_ = RxActV(pool_dy), pool_stride_ = RxI3V(pool_stride), d_residual_ = RxActV(d_residual), dy_ = RxActV(dy)](void* s) { return rx_instnorm_act_bwd_res(dt, g_.p(), y_.p(), stats, out_.p(), slope, pool_dy_.p(), pool_stride_.v, d_residual_.p(), dy_.p(), ws, ws_bytes, s); });
+  int rc;
+  if ((rc = check_vec_channels(g, dt, "rx_instnorm_act_bwd_res(g)"))) return rc;
+  if ((rc = check_vec_channels(y, dt, "rx_instnorm_act_bwd_res(y)"))) return rc;
+  if ((rc = check_vec_channels(out, dt, "rx_instnorm_act_bwd_res(out)"))) return rc;
+  if ((rc = check_vec_channels(dy, dt, "rx_instnorm_act_bwd_res(dy)"))) return rc;
+  if ((rc = check_vec_channels(d_residual, dt, "rx_instnorm_act_bwd_res(d_residual)"))) return rc;
+  if (!stats || !ws || !same_geom(y, g) || !same_geom(y, dy) || !same_geom(y, out) || !same_geom(y, d_residual))
+    RX_FAIL(RX_EINVAL, "rx_instnorm_act_bwd_res: bad arguments");
+  if (d_residual->ptr == dy->ptr) RX_FAIL(RX_EINVAL, "rx_instnorm_act_bwd_res: d_residual and dy must be different buffers");
+  if (pool_dy) {
+    if ((rc = check_vec_channels(pool_dy, dt, "rx_instnorm_act_bwd_res(pool_dy)"))) return rc;
+    if ((rc = check_pool(y, pool_dy, pool_stride, "rx_instnorm_act_bwd_res"))) return rc;
+  }
+  const long V = rx_act_voxels(y);
+  const int N = y->n, C = y->c;
+  size_t need = rx_reduce_ws_bytes(N, V, C, 2) + (size_t)N * C * 2 * sizeof(float);
+  if (ws_bytes < need) RX_FAIL(RX_EWORKSPACE, "rx_instnorm_act_bwd_res: workspace too small (%zu < %zu)", ws_bytes, need);
+  float* partial = (float*)ws;
+  float* m12 = (float*)((char*)ws + rx_align_up(rx_reduce_ws_bytes(N, V, C, 2) - 256, 256));
+  hipStream_t st = (hipStream_t)stream;
+  RX_DISPATCH_DTYPE(dt, T, {
+    constexpr int P = Elem<T>::PER16;
+    ReducePlan p = rx_reduce_plan(V, C, P);
+    int CV = C / P, VP = 256 / CV;
+    size_t lds = (size_t)2 * (VP > 4 ? VP : 4) * C * sizeof(float);
+    if (pool_dy) {
+      InBwdResOp<T, true> op{make_view<T>(g), make_view<T>(y), make_view<T>(out), make_view<T>(pool_dy), (T*)d_residual->ptr,
+                             V * (long)d_residual->ld, d_residual->ld, stats, C, slope, y->y, y->x, pool_dy->y, pool_dy->x,
+                             pool_stride[0], pool_stride[1], pool_stride[2], 1.f / (float)(pool_stride[0] * pool_stride[1] * pool_stride[2]), {}, {}};
+      hipLaunchKernelGGL((colreduce_kernel<T, 2, InBwdResOp<T, true>>), dim3(p.nchunks, N), dim3(256), lds, st, op, (int)V, C, p.chunk_vox, partial);
+    } else {
+      InBwdResOp<T, false> op{make_view<T>(g), make_view<T>(y), make_view<T>(out), make_view<T>(y), (T*)d_residual->ptr,
+                              V * (long)d_residual->ld, d_residual->ld, stats, C, slope, y->y, y->x, 1, 1, 1, 1, 1, 1.f, {}, {}};
+      hipLaunchKernelGGL((colreduce_kernel<T, 2, InBwdResOp<T, false>>), dim3(p.nchunks, N), dim3(256), lds, st, op, (int)V, C, p.chunk_vox, partial);
+    }
+    fin_launch(st, (const float*)partial, N, p.nchunks, 2, C, (double)V, 0.f, (int)FIN_MEAN2, m12);
+    int G = sweep_grid(V * CV, CV);
+    // apply: dy = rstd * (g' - m1 - xhat * m2) from (g', y) alone -- no mask, no residual output
+    hipLaunchKernelGGL((in_act_bwd_apply_kernel<T, false, false>), dim3(G, N), dim3(256), 0, st, (const T*)d_residual->ptr, d_residual->ld,
+                       V * d_residual->ld, (const T*)y->ptr, y->ld, V * y->ld, (const T*)nullptr, 0, 0L, stats, (const float*)m12,
+                       (T*)dy->ptr, dy->ld, V * dy->ld, (T*)nullptr, 0, 0L, (int)V, C, slope, 0);
+  });
+  RX_CHECK_LAUNCH("rx_instnorm_act_bwd_res");
+  return RX_OK;
+}
+
 // ---- InstanceNorm backward with the two means supplied by the caller ------------------------------------------------
 // (rx_conv3d_bwd_data_instats: the persistent backward-data kernel accumulates sum g' and sum g'*(y - mean) in its epilogue)
 __global__ __launch_bounds__(256) void inbwd_fused_finalize(const float* __restrict__ partial, int N, int nchunks, int C, double V,

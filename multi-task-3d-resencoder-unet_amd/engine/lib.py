@@ -63,6 +63,7 @@ _SIGNATURES = {
     "rx_instnorm_fwd": (c_int, [c_int, _P, c_float, c_void_p, _P, _P, c_float, c_void_p, c_size_t, c_void_p]),
     "rx_instnorm_act_bwd": (c_int, [c_int, _P, _P, c_void_p, _P, c_float, _P, _P, c_int, c_void_p, c_size_t,
                                     c_void_p]),
+    "rx_instnorm_act_bwd_res": (c_int, [c_int, _P, _P, c_void_p, _P, c_float, _P, I3, _P, _P, c_void_p, c_size_t, c_void_p]),
     "rx_se_workspace": (c_size_t, [_P]),
     "rx_se_gate_fwd": (c_int, [c_int, _P, c_void_p, c_void_p, _PSE, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                c_void_p]),

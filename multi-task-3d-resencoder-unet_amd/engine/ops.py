@@ -449,6 +449,16 @@ def instnorm_act_bwd(g, y, stats, out, dy, slope=0.01, d_residual=None, accumula
                                      int(accumulate_residual), *_ws_args(ws), stream_ptr()), "rx_instnorm_act_bwd")
 
 
+def instnorm_act_bwd_res(g, y, stats, out, dy, d_residual, slope=0.01, pool_dy=None, pool_stride=(1, 1, 1), ws=None):
+    """residual-block epilogue backward with the masked gradient written once into `d_residual` (rx_instnorm_act_bwd_res);
+    pool_dy: gradient of the next stage's skip-path AvgPool, added on the fly"""
+    ws = workspace() if ws is None else ws
+    check(load().rx_instnorm_act_bwd_res(_code(y.dtype), byref(g.desc()), byref(y.desc()), _ptr(stats), byref(out.desc()),
+                                         float(slope), byref(pool_dy.desc()) if pool_dy is not None else None, I3(*pool_stride),
+                                         byref(d_residual.desc()), byref(dy.desc()), *_ws_args(ws), stream_ptr()),
+          "rx_instnorm_act_bwd_res")
+
+
 # ---- SqueezeExcite / DropPath fused with InstanceNorm + residual + LeakyReLU ----------------------
 def _se_params(se):
     """se: dict(w1, b1, w2, b2, rd, keep_x) of fp32 device tensors, or None (DropPath only)"""
@@ -643,6 +653,9 @@ instnorm_fwd = _hbm("in_fwd(stats+apply)", lambda y, stats, out, slope=0.01, res
 instnorm_act_bwd = _hbm("in_act_bwd(colreduce+apply)",
                         lambda g, y, stats, out, dy, slope=0.01, d_residual=None, accumulate_residual=False, ws=None:
                         _bwd_bytes(g, y, out, dy, d_residual, accumulate_residual))(instnorm_act_bwd)
+instnorm_act_bwd_res = _hbm("in_act_bwd_res(colreduce+apply)",
+                            lambda g, y, stats, out, dy, d_residual, slope=0.01, pool_dy=None, pool_stride=(1, 1, 1), ws=None:
+                            _tb(g) + _tb(y) + _tb(out) + _tb(dy) + _tb(d_residual) + _tb(pool_dy))(instnorm_act_bwd_res)
 instnorm_act_bwd_apply = _hbm("in_act_bwd_apply",
                               lambda g, y, stats, out, dy, m12, slope=0.01, d_residual=None, accumulate_residual=False:
                               _bwd_bytes(g, y, out, dy, d_residual, accumulate_residual))(instnorm_act_bwd_apply)

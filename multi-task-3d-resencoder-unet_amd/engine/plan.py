@@ -894,6 +894,26 @@ class Plan:
                         b.append(gistep)
                         continue
 
+                    # residual-block epilogue whose residual gradient starts here: the masked gradient g' is written ONCE (by the
+                    # reduce pass, into gres) and the apply pass reads (g', y) only -- rx_instnorm_act_bwd_res, 7 tensor passes
+                    # instead of 8; if the AvgPool of the next stage's skip path was the last writer of gout, its gradient is
+                    # added on the fly and that pass (1R 1W over the full-resolution gradient) is gone too
+                    pend = getattr(out, "_pool_pending", None)
+                    out._pool_pending = None
+                    fuse_res = (gres is not None and not acc and res is not None and y.act.voxels > 512
+                                and os.environ.get("RX_FUSED_RES_BWD", "1") != "0")
+                    if pend is not None and not fuse_res:        # the deferred pool gradient runs as its own pass after all
+                        b.append(lambda pend=pend: ops.avgpool_bwd(pend["gy"], pend["gx"], pend["stride"], True))
+                        pend = None
+                    if fuse_res:
+                        def rstep(a=a, gout=gout, dy=dy, gres=gres, pend=pend):
+                            before_dy_write(dy)
+                            ops.instnorm_act_bwd_res(gout, a["y"].act, a["stats"], a["out"].act, dy, gres, a["slope"],
+                                                     pool_dy=pend["gy"] if pend is not None else None,
+                                                     pool_stride=pend["stride"] if pend is not None else (1, 1, 1))
+                        b.append(rstep)
+                        continue
+
                     def istep(a=a, gout=gout, dy=dy, gres=gres, acc=acc):
                         before_dy_write(dy)
                         # the saved output is only needed for the mask of residual blocks (sign(out) != sign(xhat) there)
@@ -987,6 +1007,14 @@ class Plan:
                     x.written = True
                     wrote(x, "pool")
                     assert y.gact is not None, "plan bug: pooled tensor has no gradient"
+                    # the pool opens a stage's skip path; x is the previous stage's last block output, whose InstanceNorm backward
+                    # is the very next step: hand the pool gradient to it instead of accumulating it in a pass of its own (above)
+                    ti = next(i for i, r in enumerate(tape) if r is rec)
+                    prev = tape[ti - 1] if ti > 0 else None
+                    if (acc and prev is not None and prev.kind == "inact" and prev.a["out"] is x and prev.a["res"] is not None
+                            and prev.a["gate"] is None and x.act.voxels > 512 and os.environ.get("RX_FUSED_POOL_BWD", "1") != "0"):
+                        x._pool_pending = dict(gy=y.gact, gx=gx, stride=a["stride"])
+                        continue
                     b.append(lambda a=a, gy=y.gact, gx=gx, acc=acc: ops.avgpool_bwd(gy, gx, a["stride"], acc))
                 elif rec.kind == "copy":
                     x, y = a["x"], a["y"]

@@ -576,3 +576,53 @@ def test_pack_multi_matches_reference_layouts(ops, dtype):
     wf2 = torch.zeros_like(wf)
     ops.pack_weights_multi([(w, kind, wf2, None)], dtype)
     assert torch.equal(wf2, wf)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("pool", [None, (2, 2, 2), (1, 2, 2)])
+def test_instnorm_act_bwd_res_masked_gradient_written_once(ops, dtype, pool):
+    """rx_instnorm_act_bwd_res (round 3): the residual-block epilogue backward with g' = g * lrelu'(out) written once into the
+    residual gradient, optionally adding the next stage's AvgPool gradient on the fly -- against (a) an fp64 restatement and
+    (b) the unfused sequence rx_avgpool_bwd(accumulate) + rx_instnorm_act_bwd it replaces.  g sits in the second half of a
+    wider buffer (the concat gradient of decoder.py:147, as in the plan)."""
+    n, c, dims, slope = 2, 64, (8, 12, 16), 0.01
+    y = to_act(ops, rnd((n, c, *dims), dtype, seed=41), dtype)
+    out = to_act(ops, rnd((n, c, *dims), dtype, seed=42), dtype)
+    g0 = rnd((n, c, *dims), dtype, seed=43, scale=0.1)
+    stats = torch.empty((n, c, 2), device="cuda")
+    ops.instnorm_stats(y, stats)
+    pd = tuple(d // s for d, s in zip(dims, pool)) if pool else None
+    pg = to_act(ops, rnd((n, c, *pd), dtype, seed=44, scale=0.1), dtype) if pool else None
+    # unfused
+    g1 = to_act(ops, g0, dtype, ld=2 * c, c0=c)
+    if pool:
+        ops.avgpool_bwd(pg, g1, pool, True)
+    dy1, dr1 = ops.Act.empty(n, *dims, c, dtype), ops.Act.empty(n, *dims, c, dtype)
+    ops.instnorm_act_bwd(g1, y, stats, out, dy1, slope, dr1, False)
+    # fused
+    g2 = to_act(ops, g0, dtype, ld=2 * c, c0=c)
+    dy2, dr2 = ops.Act.empty(n, *dims, c, dtype), ops.Act.empty(n, *dims, c, dtype)
+    ops.instnorm_act_bwd_res(g2, y, stats, out, dy2, dr2, slope, pool_dy=pg, pool_stride=pool or (1, 1, 1))
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert rel(dr2.t.float(), dr1.t.float()) < tol          # (the fused path adds the pool term before rounding)
+    assert rel(dy2.t.float(), dy1.t.float()) < 3 * tol
+    # fp64 restatement
+    gd = to_act(ops, g0, dtype).t.double()
+    if pool:
+        up = pg.t.double()
+        for ax, s in enumerate(pool):
+            up = up.repeat_interleave(s, dim=1 + ax)
+        gd = gd + up / (pool[0] * pool[1] * pool[2])
+    gd = torch.where(out.t.double() > 0, gd, gd * slope)
+    mean, rstd = stats[..., 0].double().view(n, 1, 1, 1, c), stats[..., 1].double().view(n, 1, 1, 1, c)
+    xh = (y.t.double() - mean) * rstd
+    ref = rstd * (gd - gd.mean(dim=(1, 2, 3), keepdim=True) - xh * (gd * xh).mean(dim=(1, 2, 3), keepdim=True))
+    assert rel(dr2.t.float().cpu(), gd.float().cpu()) < tol
+    assert rel(dy2.t.float().cpu(), ref.float().cpu()) < 3 * tol
+    # in place (d_residual == g) is allowed: same results
+    g3 = to_act(ops, g0, dtype)
+    dy3 = ops.Act.empty(n, *dims, c, dtype)
+    ops.instnorm_act_bwd_res(g3, y, stats, out, dy3, g3, slope, pool_dy=pg, pool_stride=pool or (1, 1, 1))
+    torch.cuda.synchronize()
+    assert torch.equal(g3.t, dr2.t) and torch.equal(dy3.t, dy2.t)
