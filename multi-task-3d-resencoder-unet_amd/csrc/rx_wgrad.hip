@@ -356,9 +356,205 @@ extern "C" int rx_conv3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* 
   return wgrad_launch(dt, dy->ptr, x->ptr, dw, g, ws, ws_bytes, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of nn.ConvTranspose3d(kernel == stride) (decoder.py:110-113):  dW[ci][co][t] = sum_v x[v][ci] dy[s*v + t][co].
+// wgrad_kernel runs one workgroup per (tap, split): the coarse tensor x is re-read for every tap (64 -> 32 at 64^3 -> 128^3:
+// 587 MB for a 335 MB problem, 222 us at 9.7 TFLOP/s).  Here a workgroup of 8 waves walks a contiguous range of 64-voxel
+// coarse tiles; per tile the x panel and the `taps` fine dy panels are staged ONCE (register-prefetched, [32 ch][64 voxels]
+// LDS panels read with ds_read_b64_tr_b16 as in wgrad_kernel) and wave w accumulates tap w: every operand byte is read from
+// HBM once.  Slabs [split][tap][Ci][Co] + the fixed-order reduce.  16-bit types, taps <= 8, (Ci/32)*(Co/32) <= 8.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ConvTWgGeom {
+  int Vq, NQ, Qy, Qx;         // coarse voxels per sample / in total, coarse Y, X
+  int R, ldr;                 // coarse channels (rows of dW)
+  long r_ss;
+  int Yf, Xf, Cc, ldc;        // fine tensor
+  long c_ss;
+  int sz, sy, sx, ntaps;
+  int q_per_split;
+};
+
+template <typename T, int NR, int NC>
+__global__ __launch_bounds__(512) void convT_wgrad_kernel(const T* __restrict__ xt, const T* __restrict__ yt, float* __restrict__ slab,
+                                                          const ConvTWgGeom g) {
+  constexpr int P = Elem<T>::PER16;              // 8
+  constexpr int BR = 32 * NR, BC = 32 * NC;
+  constexpr int XV = (64 * BR / P + 511) / 512;   // x pieces per thread per tile
+  constexpr int YV = (64 * BC / P + 511) / 512;   // dy pieces per thread per tile and tap
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* sX = reinterpret_cast<T*>(smem);             // [NR][64][32]
+  T* sY = sX + 64 * BR;                           // [tap][NC][64][32]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q_begin = blockIdx.x * g.q_per_split;
+  const int q_end = min(g.NQ, q_begin + g.q_per_split);
+
+  u32x4 xr[XV], yr[8][YV];
+  auto load_tile = [&](int q0) {
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int i = tid + 512 * j, vox = i / (BR / P), cv = i - vox * (BR / P);
+      const int q = q0 + vox;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (vox < 64 && q < q_end) {
+        const int n = q / g.Vq, vq = q - n * g.Vq;
+        v = *reinterpret_cast<const u32x4*>(xt + n * g.r_ss + (long)vq * g.ldr + cv * P);
+      }
+      xr[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < YV; ++j) {
+      const int i = tid + 512 * j, vox = i / (BC / P), cv = i - vox * (BC / P);
+      const int q = q0 + vox;
+      const bool ok = vox < 64 && q < q_end;
+      const int n = ok ? q / g.Vq : 0, vq = ok ? q - n * g.Vq : 0;
+      const int qx = vq % g.Qx, t2 = vq / g.Qx;
+      const int qy = t2 % g.Qy, qz = t2 / g.Qy;
+      const T* base = yt + n * g.c_ss + cv * P;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (ok && t < g.ntaps) {
+          const int c = t % g.sx, b = (t / g.sx) % g.sy, a = t / (g.sx * g.sy);
+          const long fv = ((long)(qz * g.sz + a) * g.Yf + (qy * g.sy + b)) * g.Xf + (qx * g.sx + c);
+          v = *reinterpret_cast<const u32x4*>(base + fv * g.ldc);
+        }
+        yr[t][j] = v;
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int i = tid + 512 * j, vox = i / (BR / P), cv = i - vox * (BR / P);
+      const int c = cv * P;
+      if (vox < 64) *reinterpret_cast<u32x4*>(sX + ((c >> 5) * 64 + vox) * 32 + (c & 31)) = xr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < YV; ++j) {
+      const int i = tid + 512 * j, vox = i / (BC / P), cv = i - vox * (BC / P);
+      const int c = cv * P;
+      if (vox < 64) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (t < g.ntaps) *reinterpret_cast<u32x4*>(sY + (long)t * 64 * BC + ((c >> 5) * 64 + vox) * 32 + (c & 31)) = yr[t][j];
+      }
+    }
+  };
+
+  f32x16 acc[NR][NC];
+#pragma unroll
+  for (int a = 0; a < NR; ++a)
+#pragma unroll
+    for (int b = 0; b < NC; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if (q_begin < q_end) load_tile(q_begin);
+  for (int q0 = q_begin; q0 < q_end; q0 += 64) {
+    __syncthreads();                      // everybody is done reading the previous tile
+    store_tile();
+    __syncthreads();
+    if (q0 + 64 < q_end) load_tile(q0 + 64);        // in flight under the MFMAs
+    if (wave < g.ntaps) {
+      const T* yb = sY + (long)wave * 64 * BC;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        u32x4 af[NR], bf[NC];
+#pragma unroll
+        for (int a = 0; a < NR; ++a) af[a] = fetch_frag<T>(sX + a * 64 * 32, ks, lane);
+#pragma unroll
+        for (int b = 0; b < NC; ++b) bf[b] = fetch_frag<T>(yb + b * 64 * 32, ks, lane);
+#pragma unroll
+        for (int a = 0; a < NR; ++a)
+#pragma unroll
+          for (int b = 0; b < NC; ++b) Mma<T>::run(acc[a][b], af[a], bf[b]);
+      }
+    }
+  }
+  if (wave < g.ntaps) {
+    const int col = lane & 31, fh = lane >> 5;
+    float* out = slab + ((long)blockIdx.x * g.ntaps + wave) * g.R * g.Cc;
+#pragma unroll
+    for (int a = 0; a < NR; ++a)
+#pragma unroll
+      for (int b = 0; b < NC; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+          out[(long)(a * 32 + row) * g.Cc + b * 32 + col] = acc[a][b][r];
+        }
+  }
+}
+
+static int convT_wgrad_splits(long NQ, size_t slab1) {
+  long ktiles = (NQ + 63) / 64;
+  long S = ktiles / 8;                    // >= 8 tiles per workgroup
+  if (S > 256) S = 256;
+  while (S > 32 && (size_t)S * slab1 > ((size_t)32 << 20)) S /= 2;      // slabs stay within ~32 MB (MALL-resident round trip)
+  if (S < 1) S = 1;
+  return (int)S;
+}
+
+// 1 = handled, 0 = not applicable (fall through to wgrad_kernel), < 0 error
+static int convT_wgrad_try(rx_dtype dt, const rx_act* x, const rx_act* dy, const int32_t stride[3], float* dw, void* ws, size_t ws_bytes,
+                           hipStream_t st) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("RX_CONVT_WGRAD");
+    on = e ? atoi(e) : 1;
+  }
+  const int taps = stride[0] * stride[1] * stride[2];
+  const int R = x->c, C = dy->c;
+  if (!on || dt == RX_F32 || taps > 8 || R % 32 || C % 32 || x->ld % 8 || dy->ld % 8 || ((uintptr_t)x->ptr & 15) || ((uintptr_t)dy->ptr & 15)) return 0;
+  const int NR = R / 32, NC = C / 32;
+  if (!((NR == 2 && NC == 1) || (NR == 4 && NC == 2) || (NR == 1 && NC == 1) || (NR == 2 && NC == 2))) return 0;
+  const long NQ = (long)x->n * rx_act_voxels(x);
+  if (NQ < 32768) return 0;               // the low-resolution layers: too few tiles to split, the generic kernel is fine there
+  const size_t slab1 = (size_t)taps * R * C * sizeof(float);
+  const int S = convT_wgrad_splits(NQ, slab1);
+  if ((size_t)S * slab1 > ws_bytes) return 0;
+  ConvTWgGeom g;
+  g.Vq = (int)rx_act_voxels(x), g.NQ = (int)NQ, g.Qy = x->y, g.Qx = x->x;
+  g.R = R, g.ldr = x->ld, g.r_ss = (long)g.Vq * x->ld;
+  g.Yf = dy->y, g.Xf = dy->x, g.Cc = C, g.ldc = dy->ld, g.c_ss = rx_act_voxels(dy) * (long)dy->ld;
+  g.sz = stride[0], g.sy = stride[1], g.sx = stride[2], g.ntaps = taps;
+  const long ktiles = (NQ + 63) / 64;
+  g.q_per_split = (int)(((ktiles + S - 1) / S) * 64);
+  const int S2 = (int)((NQ + g.q_per_split - 1) / g.q_per_split);
+  const size_t lds = (size_t)64 * (R + taps * C) * 2;
+  rx_note_kernel("convT_wgrad_kernel");
+#define RX_CTW(NR_, NC_)                                                                                                              \
+  do {                                                                                                                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convT_wgrad_kernel<T, NR_, NC_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((convT_wgrad_kernel<T, NR_, NC_>), dim3(S2), dim3(512), lds, st, (const T*)x->ptr, (const T*)dy->ptr, (float*)ws, g);            \
+  } while (0)
+#define RX_CTW_ALL()                       \
+  if (NR == 2 && NC == 1) RX_CTW(2, 1);    \
+  else if (NR == 4 && NC == 2) RX_CTW(4, 2); \
+  else if (NR == 1 && NC == 1) RX_CTW(1, 1); \
+  else RX_CTW(2, 2)
+  if (dt == RX_BF16) {
+    using T = bf16_t;
+    RX_CTW_ALL();
+  } else {
+    using T = f16_t;
+    RX_CTW_ALL();
+  }
+#undef RX_CTW_ALL
+#undef RX_CTW
+  rx_wgrad_reduce_launch((const float*)ws, S2, taps, R, C, dw, st);
+  return 1;
+}
+
 extern "C" size_t rx_convT3d_bwd_weight_workspace(const rx_act* x, const rx_act* dy, const int32_t stride[3]) {
   if (!rx_act_ok(x) || !rx_act_ok(dy)) return 0;
-  return wgrad_ws_bytes(x->c, dy->c, stride[0] * stride[1] * stride[2], (long)x->n * rx_act_voxels(x));
+  const int taps = stride[0] * stride[1] * stride[2];
+  const long NQ = (long)x->n * rx_act_voxels(x);
+  const size_t slab1 = (size_t)taps * x->c * dy->c * sizeof(float);
+  const size_t a = wgrad_ws_bytes(x->c, dy->c, taps, NQ);
+  const size_t b = (size_t)convT_wgrad_splits(NQ, slab1) * slab1 + 256;
+  return a > b ? a : b;
 }
 
 extern "C" int rx_convT3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* dy, float* dw, const int32_t stride[3], void* ws,
@@ -369,6 +565,14 @@ extern "C" int rx_convT3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act*
     if (stride[i] != 1 && stride[i] != 2) RX_FAIL(RX_EUNSUPPORTED, "rx_convT3d_bwd_weight: strides must be 1 or 2");
   if (dy->n != x->n || dy->z != x->z * stride[0] || dy->y != x->y * stride[1] || dy->x != x->x * stride[2])
     RX_FAIL(RX_EINVAL, "rx_convT3d_bwd_weight: geometry mismatch");
+  if (ws && dw) {
+    const int rc = convT_wgrad_try(dt, x, dy, stride, dw, ws, ws_bytes, (hipStream_t)stream);    // every operand byte once
+    if (rc < 0) return rc;
+    if (rc == 1) {
+      RX_CHECK_LAUNCH("rx_convT3d_bwd_weight(convT_wgrad)");
+      return RX_OK;
+    }
+  }
   // dW[ci][co][t] = sum_i x[i][ci] * dy[i*s + t][co]
   WgradGeom g;
   memset(&g, 0, sizeof(g));
