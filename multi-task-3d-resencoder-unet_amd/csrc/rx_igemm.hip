@@ -542,8 +542,6 @@ void rx_inbwd_fused_finalize_launch(const float* partial, int N, int nchunks, in
 // rx_pointwise.hip
 int rx_pointwise_try(rx_dtype dt, const rx_act* in, const void* w, const float* bias, const rx_act* out, const int32_t stride[3],
                      int accumulate, hipStream_t st);
-int rx_pointwise_gather_try(rx_dtype dt, const rx_act* fine, const void* w, const rx_act* coarse, const int32_t stride[3], int accumulate,
-                            hipStream_t st);
 // rx_dgrad_s2.hip
 int rx_dgrad_s2_halo_try(rx_dtype dt, const rx_act* dy, const void* w_bwd, const rx_act* dx, int accumulate, hipStream_t st);
 // rx_elementwise.hip
@@ -798,10 +796,6 @@ extern "C" int rx_convT3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_
   if (!rx_act_ok(dy) || !rx_act_ok(dx) || !w_bwd) RX_FAIL(RX_EINVAL, "rx_convT3d_bwd_data: bad arguments");
   int rc = checkT(stride, dx, dy, "rx_convT3d_bwd_data");
   if (rc) return rc;
-  if (rx_pointwise_gather_try(dt, dy, w_bwd, dx, stride, accumulate, (hipStream_t)stream) == 1) {     // dy once, dx once (rx_pointwise.hip)
-    RX_CHECK_LAUNCH("rx_convT3d_bwd_data(gather)");
-    return RX_OK;
-  }
   // dx[i] = sum_t dy[i*s + t] W[t]^T
   IgemmGeom g;
   memset(&g, 0, sizeof(g));

@@ -141,159 +141,3 @@ int rx_pointwise_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   return 1;
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Backward-data of nn.ConvTranspose3d(kernel == stride) (decoder.py:110-113):  dx[v][ci] = sum_t sum_co W[ci][co][t] dy[s*v + t][co]
-// -- the gather twin of pointwise_kernel.  The generic gather kernel ran it as ONE phase of `taps` single-tap K tiles with a
-// barrier pair every 64 bytes of K (0.19 ms per cfg2 step alone, 0.64 ms next to the weight-gradient stream: 0.7 TB/s).
-// Here a wave owns 32 consecutive COARSE voxels and ALL their output channels (NB blocks of 32): per tap the fine voxel's Kc
-// channels go straight from global memory into MFMA B fragments (16 bytes per lane and K step, every load of a tap batch issued
-// before the first MFMA), the weights [taps][Mo][Kc] are LDS-resident for the workgroup's life, and the taps accumulate in
-// registers -- dy is read exactly once, dx written once with 16-byte stores.  Persistent over voxel tiles.
-// ---------------------------------------------------------------------------------------------------------------------
-struct PwGatherGeom {
-  int N, Zc, Yc, Xc;         // coarse grid (output)
-  int Yf, Xf, Kc, ldf;       // fine tensor (input): rows of Kc channels
-  long fine_ss;
-  int Mo, ldo;
-  long out_ss;
-  int sz, sy, sx;
-  int accumulate;
-  int ntiles;
-};
-
-template <typename T, int NB, int KS>
-__global__ __launch_bounds__(256) void pw_gather_kernel(const T* __restrict__ in, const T* __restrict__ w, T* __restrict__ out, const PwGatherGeom g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [taps][Mo][Kc * 2 + 16 bytes]
-  constexpr int TB = (16 / KS) < 8 ? (16 / KS) : 8;                         // taps per batch: <= 16 fragments in flight per lane
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fr = lane & 31, fh = lane >> 5;
-  const int ntaps = g.sz * g.sy * g.sx;
-  const int pitch = g.Kc * 2 + 16;
-  const int cpr = g.Kc / 8;
-  const int Mo = 32 * NB;
-  for (int i = tid; i < ntaps * Mo * cpr; i += 256) {
-    const int c = i % cpr, row = i / cpr;             // row = t * Mo + m
-    *reinterpret_cast<u32x4*>(smem + row * pitch + c * 16) = *reinterpret_cast<const u32x4*>(w + (long)row * g.Kc + c * 8);
-  }
-  __syncthreads();
-  const long V = (long)g.Zc * g.Yc * g.Xc, NV = (long)g.N * V;
-  const unsigned char* wrow = smem + fr * pitch + fh * 16;
-  for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-    const long q = (long)tile * 128 + wave * 32 + fr;
-    const bool ok = q < NV;
-    const int n = ok ? (int)(q / V) : 0;
-    const long v = ok ? q - (long)n * V : 0;
-    const int x = (int)(v % g.Xc), y = (int)((v / g.Xc) % g.Yc), z = (int)(v / ((long)g.Xc * g.Yc));
-    const T* in_n = in + (long)n * g.fine_ss + fh * 8;
-    T* op = out + (long)n * g.out_ss + v * g.ldo;
-    u32x2 oldv[NB][4];
-    if (g.accumulate && ok) {
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) oldv[nb][g4] = *reinterpret_cast<const u32x2*>(op + nb * 32 + 8 * g4 + 4 * fh);
-    }
-    f32x16 acc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    for (int t0 = 0; t0 < ntaps; t0 += TB) {
-      u32x4 bq[TB][KS];
-#pragma unroll
-      for (int tt = 0; tt < TB; ++tt) {
-        const int t = t0 + tt;
-        const int c = t % g.sx, b = (t / g.sx) % g.sy, a = t / (g.sx * g.sy);
-        const long fv = ((long)(z * g.sz + a) * g.Yf + (y * g.sy + b)) * g.Xf + (x * g.sx + c);
-        const T* ip = in_n + fv * g.ldf;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) bq[tt][ks] = (ok && t < ntaps) ? *reinterpret_cast<const u32x4*>(ip + ks * 16) : u32x4{0u, 0u, 0u, 0u};
-      }
-#pragma unroll
-      for (int tt = 0; tt < TB; ++tt) {
-        if (t0 + tt < ntaps) {
-          const unsigned char* wt = wrow + (long)(t0 + tt) * Mo * pitch;
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) Mma<T>::run(acc[nb], *reinterpret_cast<const u32x4*>(wt + nb * 32 * pitch + ks * 32), bq[tt][ks]);
-        }
-      }
-    }
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      u32x2 piece[4];
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        T vals[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float f = acc[nb][4 * g4 + i];
-          if (g.accumulate) f += Elem<T>::to_f(reinterpret_cast<const T*>(&oldv[nb][g4])[i]);
-          vals[i] = Elem<T>::from_f(f);
-        }
-        piece[g4] = *reinterpret_cast<u32x2*>(vals);
-      }
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        const u32x4 o16 = rx_pair16(piece[2 * pr], piece[2 * pr + 1]);
-        if (ok) *reinterpret_cast<u32x4*>(op + nb * 32 + 16 * pr + 8 * fh) = o16;
-      }
-    }
-  }
-}
-
-// 1 = handled.  fine: dy on the fine grid; coarse: dx; w = [taps][Mo = coarse channels][Kc = fine channels] (the transposed conv's
-// backward pack).  16-bit types, (Mo, Kc) in {(64, 32), (128, 64), (32, 32), (64, 64)} and the weights must fit the LDS.
-int rx_pointwise_gather_try(rx_dtype dt, const rx_act* fine, const void* w, const rx_act* coarse, const int32_t stride[3], int accumulate,
-                            hipStream_t st) {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("RX_POINTWISE_GATHER");
-    on = e ? atoi(e) : 1;
-  }
-  if (!on || dt == RX_F32 || fine->cs || coarse->cs) return 0;
-  const int taps = stride[0] * stride[1] * stride[2];
-  const int Kc = fine->c, Mo = coarse->c;
-  if (fine->ld % 8 || coarse->ld % 8 || ((uintptr_t)fine->ptr & 15) || ((uintptr_t)coarse->ptr & 15) || ((uintptr_t)w & 15)) return 0;
-  const int NB = Mo / 32, KS = Kc / 16;
-  if (Mo % 32 || Kc % 16 || !((NB == 2 && KS == 2) || (NB == 4 && KS == 4) || (NB == 1 && KS == 2) || (NB == 2 && KS == 4))) return 0;
-  const size_t lds = (size_t)taps * Mo * (Kc * 2 + 16);
-  if (lds > 150 * 1024) return 0;
-  const long NV = (long)coarse->n * rx_act_voxels(coarse);
-  if (NV < 4096) return 0;
-  PwGatherGeom g;
-  g.N = coarse->n, g.Zc = coarse->z, g.Yc = coarse->y, g.Xc = coarse->x;
-  g.Yf = fine->y, g.Xf = fine->x, g.Kc = Kc, g.ldf = fine->ld, g.fine_ss = rx_act_voxels(fine) * (long)fine->ld;
-  g.Mo = Mo, g.ldo = coarse->ld, g.out_ss = rx_act_voxels(coarse) * (long)coarse->ld;
-  g.sz = stride[0], g.sy = stride[1], g.sx = stride[2];
-  g.accumulate = accumulate;
-  g.ntiles = (int)((NV + 127) / 128);
-  int per_cu = (int)((160 * 1024) / (lds + 1024));
-  if (per_cu > 4) per_cu = 4;
-  if (per_cu < 1) per_cu = 1;
-  int gx = 256 * per_cu;
-  if (gx > g.ntiles) gx = g.ntiles;
-  rx_note_kernel("pw_gather_kernel");
-#define RX_PWG(NB_, KS_)                                                                                                                  \
-  do {                                                                                                                                    \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gather_kernel<T, NB_, KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    hipLaunchKernelGGL((pw_gather_kernel<T, NB_, KS_>), dim3(gx), dim3(256), lds, st, (const T*)fine->ptr, (const T*)w, (T*)coarse->ptr, g);         \
-  } while (0)
-#define RX_PWG_ALL()                    \
-  if (NB == 2 && KS == 2) RX_PWG(2, 2); \
-  else if (NB == 4 && KS == 4) RX_PWG(4, 4); \
-  else if (NB == 1 && KS == 2) RX_PWG(1, 2); \
-  else RX_PWG(2, 4)
-  if (dt == RX_BF16) {
-    using T = bf16_t;
-    RX_PWG_ALL();
-  } else {
-    using T = f16_t;
-    RX_PWG_ALL();
-  }
-#undef RX_PWG_ALL
-#undef RX_PWG
-  return 1;
-}

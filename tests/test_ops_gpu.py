@@ -135,8 +135,8 @@ CONVT_CASES = [
     (64, 32, (12, 18, 20), (2, 2, 2)),         # >= 4096 voxels: the streaming pointwise kernel (x once, y once)
     (256, 128, (8, 9, 16), (2, 2, 2)),         # 8 taps x 256 channels: 132 KB of weights would leave one workgroup per CU -> gather kernel
     (128, 64, (10, 16, 24), (1, 2, 2)),        # anisotropic stride
-    (64, 32, (16, 32, 40), (2, 2, 2)),         # >= 32768 coarse voxels: convT_wgrad_kernel (every operand byte once), pw_gather_kernel
-    (128, 64, (16, 32, 34), (2, 2, 2)),        # the same on the 4 x 2 block instantiation (80 KB of LDS panels, 147 KB of gather weights)
+    (64, 32, (16, 32, 40), (2, 2, 2)),         # >= 32768 coarse voxels: convT_wgrad_kernel (every operand byte once)
+    (128, 64, (16, 32, 34), (2, 2, 2)),        # the same on the 4 x 2 block instantiation (80 KB of LDS panels)
     (64, 64, (20, 32, 32), (1, 2, 2)),         # four taps: waves 4..7 of the weight-gradient workgroup only stage
 ]
 
@@ -169,10 +169,6 @@ def test_convT3d_fwd_bwd(ops, dtype, case):
     dxa = ops.Act.zeros(n, *dims, ci, dtype)
     ops.convT3d_bwd_data(gya, w_bwd, dxa, s)
     nv = n * dims[0] * dims[1] * dims[2]
-    gather = dtype != torch.float32 and nv >= 4096 and (ci // 32, co // 16) in ((2, 2), (4, 4), (1, 2), (2, 4)) \
-        and s[0] * s[1] * s[2] * ci * (co * 2 + 16) <= 150 * 1024
-    if gather:
-        assert last_kernel(ops) == "pw_gather_kernel"
     assert rel(dxa.to_ncdhw(), xr.grad) < TOL[dtype]
     ops.convT3d_bwd_data(gya, w_bwd, dxa, s, True)                    # accumulate (a second decoder's gradient)
     assert rel(dxa.to_ncdhw(), 2 * xr.grad) < 2 * TOL[dtype]
