@@ -166,9 +166,15 @@ static inline bool rx_act_ok_planar(const rx_act* a) {
 }
 
 // ---- tap tables and MFMA wrappers shared by the implicit-GEMM and weight-gradient kernels ------
+// kernel sizes 1..7 and strides 1..4 per axis (the reference passes any `kernel_sizes` / `strides` of a manual model_config
+// straight to Conv(k, stride, pad = (k-1)//2), build_network_from_config.py:85-148): up to 7^3 = 343 taps per launch, so the
+// weight index needs 9 bits and the tables live in the kernel arguments (RX_MAX_TAPS x 8 bytes, within the 4 KB kernarg limit)
+#define RX_MAX_TAPS 344
+#define RX_MAX_KERNEL 7
+#define RX_MAX_STRIDE 4
 struct RxTap {
-  int8_t dz, dy, dx;
-  uint8_t w;
+  int8_t dz, dy, dx, pad_;
+  uint16_t w, pad2_;
 };
 
 // one 32x32 accumulator update from two 16-byte operand fragments (lane = row/col (lane&31),

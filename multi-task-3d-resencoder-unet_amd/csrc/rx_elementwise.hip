@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ 
 
 static int check_pool(const rx_act* big, const rx_act* small, const int32_t f[3], const char* who) {
   for (int i = 0; i < 3; ++i)
-    if (f[i] != 1 && f[i] != 2) RX_FAIL(RX_EUNSUPPORTED, "%s: pool factor must be 1 or 2", who);
+    if (f[i] < 1 || f[i] > RX_MAX_STRIDE) RX_FAIL(RX_EUNSUPPORTED, "%s: pool factor must be 1..%d per axis", who, RX_MAX_STRIDE);
   if (big->n != small->n || big->c != small->c || big->z != small->z * f[0] || big->y != small->y * f[1] || big->x != small->x * f[2])
     RX_FAIL(RX_EINVAL, "%s: geometry mismatch (%d,%d,%d)/(%d,%d,%d)", who, big->z, big->y, big->x, small->z, small->y, small->x);
   return RX_OK;
@@ -2004,6 +2004,27 @@ __device__ __forceinline__ void pack_tile(const float* __restrict__ w, int A, in
   }
 }
 
+// more than 27 taps (5- / 7-wide kernels, stride-3 / -4 transposed convs): the [TT][32][40] LDS tile of pack_tile does not fit;
+// these layers are rare and small -- one thread per weight, coalesced reads, scattered 2-byte writes
+template <typename T>
+__global__ __launch_bounds__(256) void pack_naive_kernel(const float* __restrict__ w, int A, int B, int TT, T* __restrict__ same, T* __restrict__ swp) {
+  const long total = (long)A * B * TT;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int t = (int)(i % TT);
+    const long ab = i / TT;
+    const int b = (int)(ab % B), a = (int)(ab / B);
+    const T v = Elem<T>::from_f(w[i]);
+    if (same) same[((long)t * A + a) * B + b] = v;
+    if (swp) swp[((long)t * B + b) * A + a] = v;
+  }
+}
+template <typename T>
+static void pack_naive_launch(hipStream_t st, const float* w, int A, int B, int TT, void* same, void* swp) {
+  long blocks = ((long)A * B * TT + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((pack_naive_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, w, A, B, TT, (T*)same, (T*)swp);
+}
+
 template <typename T>
 __global__ __launch_bounds__(RX_PACK_THREADS) void pack_kernel(const float* __restrict__ w, int A, int B, int TT, unsigned inv_tt, T* __restrict__ same,
                                                    int flip_same, T* __restrict__ swp, int flip_swap) {
@@ -2406,8 +2427,14 @@ extern "C" int rx_grad_norm_clip(int count, const float* const* grad, const long
 
 static int pack_generic(rx_dtype dt, const float* w, int A, int B, int TT, void* same, int flip_same, void* swp, int flip_swap,
                         void* stream) {
-  if (!w || A < 1 || B < 1 || TT < 1 || TT > 27) RX_FAIL(RX_EINVAL, "rx_pack: bad arguments");
+  if (!w || A < 1 || B < 1 || TT < 1 || TT > RX_MAX_TAPS - 1) RX_FAIL(RX_EINVAL, "rx_pack: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  if (TT > 27) {
+    if (flip_same || flip_swap) RX_FAIL(RX_EUNSUPPORTED, "rx_pack: flipped packs exist for <= 27 taps only");
+    RX_DISPATCH_DTYPE(dt, T, pack_naive_launch<T>(st, w, A, B, TT, same, swp));
+    RX_CHECK_LAUNCH("rx_pack(naive)");
+    return RX_OK;
+  }
   RX_DISPATCH_DTYPE(dt, T, {
     size_t lds = (size_t)TT * 32 * RX_PACK_PB * sizeof(T);
     const unsigned inv_tt = (unsigned)(((1ull << 32) + TT - 1) / TT);   // r / TT == umulhi(r, inv_tt) for r < 2^16
@@ -2444,9 +2471,32 @@ extern "C" int rx_pack_multi(rx_dtype dt, int count, const float* const* w, cons
                 stream, __func__);
   }
   for (int i = 0; i < count; ++i)
-    if (!w[i] || A[i] < 1 || B[i] < 1 || taps[i] < 1 || taps[i] > 27 || (kind[i] != 0 && kind[i] != 1))
+    if (!w[i] || A[i] < 1 || B[i] < 1 || taps[i] < 1 || taps[i] > RX_MAX_TAPS - 1 || (kind[i] != 0 && kind[i] != 1))
       RX_FAIL(RX_EINVAL, "rx_pack_multi: bad entry %d", i);
   hipStream_t st = (hipStream_t)stream;
+  {   // entries with more than 27 taps: one naive launch each, the rest goes through the table kernel
+    std::vector<const float*> w2;
+    std::vector<int> kind2, A2, B2, taps2;
+    std::vector<void*> f2, b2;
+    bool any_big = false;
+    for (int i = 0; i < count; ++i) {
+      if (taps[i] > 27) {
+        any_big = true;
+        void* same = kind[i] == 0 ? w_fwd[i] : w_bwd[i];
+        void* swp = kind[i] == 0 ? w_bwd[i] : w_fwd[i];
+        RX_DISPATCH_DTYPE(dt, T, pack_naive_launch<T>(st, w[i], A[i], B[i], taps[i], same, swp));
+      } else {
+        w2.push_back(w[i]), kind2.push_back(kind[i]), A2.push_back(A[i]), B2.push_back(B[i]), taps2.push_back(taps[i]);
+        f2.push_back(w_fwd[i]), b2.push_back(w_bwd[i]);
+      }
+    }
+    if (any_big) {
+      RX_CHECK_LAUNCH("rx_pack_multi(naive)");
+      if (w2.empty()) return RX_OK;
+      // (the nested call must not record itself again: rx_scope__ above already pushed this whole call)
+      return rx_pack_multi(dt, (int)w2.size(), w2.data(), kind2.data(), A2.data(), B2.data(), taps2.data(), f2.data(), b2.data(), stream);
+    }
+  }
   for (int i0 = 0; i0 < count; i0 += RX_PM_MAX) {
     PackMulti t;
     memset(&t, 0, sizeof(t));

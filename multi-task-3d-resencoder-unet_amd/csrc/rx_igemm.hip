@@ -42,7 +42,7 @@ struct IgemmGeom {
   int osz, osy, osx;
   int accumulate, ksplit, nph, total_mtiles;
   IgemmPhase ph[8];
-  RxTap taps[32];
+  RxTap taps[RX_MAX_TAPS];
 };
 
 __device__ inline int swz(int row, int chunk) { return row * 4 + (chunk ^ ((row >> 2) & 3)); }
@@ -552,8 +552,8 @@ static bool is_333_s1(const int32_t k[3], const int32_t s[3]) {
 
 static int check13(const int32_t k[3], const int32_t s[3], const char* who) {
   for (int i = 0; i < 3; ++i) {
-    if (k[i] != 1 && k[i] != 3) RX_FAIL(RX_EUNSUPPORTED, "%s: kernel sizes must be 1 or 3", who);
-    if (s[i] != 1 && s[i] != 2) RX_FAIL(RX_EUNSUPPORTED, "%s: strides must be 1 or 2", who);
+    if (k[i] < 1 || k[i] > RX_MAX_KERNEL) RX_FAIL(RX_EUNSUPPORTED, "%s: kernel sizes must be 1..%d per axis (got %d)", who, RX_MAX_KERNEL, k[i]);
+    if (s[i] < 1 || s[i] > RX_MAX_STRIDE) RX_FAIL(RX_EUNSUPPORTED, "%s: strides must be 1..%d per axis (got %d)", who, RX_MAX_STRIDE, s[i]);
   }
   return RX_OK;
 }
@@ -605,7 +605,7 @@ extern "C" int rx_conv3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, co
       for (int c = 0; c < kernel[2]; ++c) {
         RxTap& t = g.taps[P.ntaps];
         t.dz = (int8_t)(a - pz), t.dy = (int8_t)(b - py), t.dx = (int8_t)(c - px);
-        t.w = (uint8_t)P.ntaps;
+        t.w = (uint16_t)P.ntaps;
         ++P.ntaps;
       }
   return igemm_launch(dt, x->ptr, w_fwd, bias, y->ptr, g, x->n, ws, wsb, (hipStream_t)stream);
@@ -711,14 +711,19 @@ extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_b
   const int k[3] = {kernel[0], kernel[1], kernel[2]}, s[3] = {stride[0], stride[1], stride[2]};
   const int p[3] = {(k[0] - 1) / 2, (k[1] - 1) / 2, (k[2] - 1) / 2};
   const int din[3] = {dx->z, dx->y, dx->x};
-  // dx[s*q + r] = sum_{t : (r+p-t) % s == 0} dy[q + (r+p-t)/s] * W[t]^T      per axis; one PHASE per parity class r
+  // dx[s*q + r] = sum_{t : (r+p-t) % s == 0} dy[q + (r+p-t)/s] * W[t]^T      per axis; one PHASE per parity class r.
+  // Up to 8 phases and RX_MAX_TAPS taps per launch: stride 2 is one launch (8 classes, 27 taps), strides 3 / 4 or 5..7-wide
+  // kernels take a few (the classes write disjoint voxels, so the launches are independent).
   IgemmGeom g;
-  memset(&g, 0, sizeof(g));
-  geom_in(g, dy);
-  geom_out(g, dx);
-  g.isz = g.isy = g.isx = 1;
-  g.osz = s[0], g.osy = s[1], g.osx = s[2];
-  g.accumulate = accumulate;
+  auto reset = [&]() {
+    memset(&g, 0, sizeof(g));
+    geom_in(g, dy);
+    geom_out(g, dx);
+    g.isz = g.isy = g.isx = 1;
+    g.osz = s[0], g.osy = s[1], g.osx = s[2];
+    g.accumulate = accumulate;
+  };
+  reset();
   int ntap_total = 0;
   for (int r0 = 0; r0 < s[0]; ++r0)
     for (int r1 = 0; r1 < s[1]; ++r1)
@@ -727,10 +732,24 @@ extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_b
         int Q[3];
         for (int a = 0; a < 3; ++a) Q[a] = (din[a] - r[a] + s[a] - 1) / s[a];
         if (Q[0] * Q[1] * Q[2] <= 0) continue;
+        int cnt = 0;
+        for (int a = 0; a < k[0]; ++a)
+          if ((r0 + p[0] - a) % s[0] == 0)
+            for (int b = 0; b < k[1]; ++b)
+              if ((r1 + p[1] - b) % s[1] == 0)
+                for (int c = 0; c < k[2]; ++c)
+                  if ((r2 + p[2] - c) % s[2] == 0) ++cnt;
+        if (g.nph == 8 || ntap_total + cnt > RX_MAX_TAPS) {
+          rc = igemm_launch(dt, dy->ptr, w_bwd, nullptr, dx->ptr, g, dx->n, ws, wsb, (hipStream_t)stream);
+          if (rc) return rc;
+          reset();
+          ntap_total = 0;
+        }
         IgemmPhase& P = g.ph[g.nph++];
         P.Qz = Q[0], P.Qy = Q[1], P.Qx = Q[2], P.Vq = Q[0] * Q[1] * Q[2];
         P.opz = r0, P.opy = r1, P.opx = r2;
         P.tap0 = ntap_total;
+        // a class without any tap (kernel narrower than the stride) still has to WRITE its voxels: zeros (or keep dx when accumulating)
         for (int a = 0; a < k[0]; ++a) {
           if ((r0 + p[0] - a) % s[0]) continue;
           for (int b = 0; b < k[1]; ++b) {
@@ -741,7 +760,7 @@ extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_b
               t.dz = (int8_t)((r0 + p[0] - a) / s[0]);
               t.dy = (int8_t)((r1 + p[1] - b) / s[1]);
               t.dx = (int8_t)((r2 + p[2] - c) / s[2]);
-              t.w = (uint8_t)((a * k[1] + b) * k[2] + c);
+              t.w = (uint16_t)((a * k[1] + b) * k[2] + c);
               ++P.ntaps;
             }
           }
@@ -752,7 +771,7 @@ extern "C" int rx_conv3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_b
 
 static int checkT(const int32_t s[3], const rx_act* small, const rx_act* big, const char* who) {
   for (int i = 0; i < 3; ++i)
-    if (s[i] != 1 && s[i] != 2) RX_FAIL(RX_EUNSUPPORTED, "%s: strides must be 1 or 2", who);
+    if (s[i] < 1 || s[i] > RX_MAX_STRIDE) RX_FAIL(RX_EUNSUPPORTED, "%s: strides must be 1..%d per axis", who, RX_MAX_STRIDE);
   if (small->n != big->n || big->z != small->z * s[0] || big->y != small->y * s[1] || big->x != small->x * s[2])
     RX_FAIL(RX_EINVAL, "%s: geometry mismatch", who);
   return RX_OK;
@@ -768,23 +787,31 @@ extern "C" int rx_convT3d_fwd(rx_dtype dt, const rx_act* x, const void* w_fwd, c
     RX_CHECK_LAUNCH("rx_convT3d_fwd(pointwise)");
     return RX_OK;
   }
-  // y[i*s + t] = sum_ci x[i] W[ci][co][t] + b : one single-tap PHASE per kernel position t, one launch
+  // y[i*s + t] = sum_ci x[i] W[ci][co][t] + b : one single-tap PHASE per kernel position t, up to 8 per launch
   IgemmGeom g;
-  memset(&g, 0, sizeof(g));
-  geom_in(g, x);
-  geom_out(g, y);
-  g.isz = g.isy = g.isx = 1;
-  g.osz = stride[0], g.osy = stride[1], g.osx = stride[2];
+  auto reset = [&]() {
+    memset(&g, 0, sizeof(g));
+    geom_in(g, x);
+    geom_out(g, y);
+    g.isz = g.isy = g.isx = 1;
+    g.osz = stride[0], g.osy = stride[1], g.osx = stride[2];
+  };
+  reset();
   for (int a = 0; a < stride[0]; ++a)
     for (int b = 0; b < stride[1]; ++b)
       for (int c = 0; c < stride[2]; ++c) {
+        if (g.nph == 8) {
+          rc = igemm_launch(dt, x->ptr, w_fwd, bias, y->ptr, g, x->n, ws, wsb, (hipStream_t)stream);
+          if (rc) return rc;
+          reset();
+        }
         IgemmPhase& P = g.ph[g.nph];
         P.Qz = x->z, P.Qy = x->y, P.Qx = x->x, P.Vq = (int)rx_act_voxels(x);
         P.opz = a, P.opy = b, P.opx = c;
         P.tap0 = g.nph, P.ntaps = 1;
         RxTap& t = g.taps[g.nph];
         t.dz = t.dy = t.dx = 0;
-        t.w = (uint8_t)((a * stride[1] + b) * stride[2] + c);
+        t.w = (uint16_t)((a * stride[1] + b) * stride[2] + c);
         ++g.nph;
       }
   return igemm_launch(dt, x->ptr, w_fwd, bias, y->ptr, g, x->n, ws, wsb, (hipStream_t)stream);
@@ -812,7 +839,7 @@ extern "C" int rx_convT3d_bwd_data(rx_dtype dt, const rx_act* dy, const void* w_
       for (int c = 0; c < stride[2]; ++c) {
         RxTap& t = g.taps[P.ntaps];
         t.dz = (int8_t)a, t.dy = (int8_t)b, t.dx = (int8_t)c;
-        t.w = (uint8_t)P.ntaps;
+        t.w = (uint16_t)P.ntaps;
         ++P.ntaps;
       }
   return igemm_launch(dt, dy->ptr, w_bwd, nullptr, dx->ptr, g, dx->n, ws, wsb, (hipStream_t)stream);

@@ -29,7 +29,7 @@ struct WgradGeom {
   long x_ss;
   int isz, isy, isx;
   int ntaps, ksplit, q_per_split, tiles_c;
-  RxTap taps[27];
+  RxTap taps[RX_MAX_TAPS];
 };
 
 
@@ -305,7 +305,7 @@ static int conv_out_dim(int in, int k, int s) { return (in + 2 * ((k - 1) / 2) -
 // shared with rx_wgrad_halo.hip
 void rx_wgrad_reduce_launch(const float* slab, int S, int T_, int R, int C, float* dw, hipStream_t st) {
   long RC = (long)R * C;
-  if (S >= 8)
+  if (S >= 8 || T_ > 27)       // (wgrad_reduce transposes a [256][T <= 27] tile through LDS)
     hipLaunchKernelGGL(wgrad_reduce_manysplits, dim3((unsigned)((RC + 255) / 256), T_), dim3(256), 0, st, slab, S, T_, R, C, dw);
   else
     hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((RC + 255) / 256)), dim3(256), 0, st, slab, S, T_, R, C, dw);
@@ -326,8 +326,8 @@ extern "C" int rx_conv3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* 
   RX_RECORD(stream, [=, x_ = RxActV(x), dy_ = RxActV(dy), kernel_ = RxI3V(kernel), stride_ = RxI3V(stride)](void* s) { return rx_conv3d_bwd_weight(dt, x_.p(), dy_.p(), dw, kernel_.v, stride_.v, ws, ws_bytes, s); });
   if (!rx_act_ok_planar(x) || !rx_act_ok(dy)) RX_FAIL(RX_EINVAL, "rx_conv3d_bwd_weight: bad arguments");
   for (int i = 0; i < 3; ++i) {
-    if (kernel[i] != 1 && kernel[i] != 3) RX_FAIL(RX_EUNSUPPORTED, "rx_conv3d_bwd_weight: kernel sizes must be 1 or 3");
-    if (stride[i] != 1 && stride[i] != 2) RX_FAIL(RX_EUNSUPPORTED, "rx_conv3d_bwd_weight: strides must be 1 or 2");
+    if (kernel[i] < 1 || kernel[i] > RX_MAX_KERNEL) RX_FAIL(RX_EUNSUPPORTED, "rx_conv3d_bwd_weight: kernel sizes must be 1..%d per axis", RX_MAX_KERNEL);
+    if (stride[i] < 1 || stride[i] > RX_MAX_STRIDE) RX_FAIL(RX_EUNSUPPORTED, "rx_conv3d_bwd_weight: strides must be 1..%d per axis", RX_MAX_STRIDE);
   }
   if (dy->n != x->n || dy->z != conv_out_dim(x->z, kernel[0], stride[0]) || dy->y != conv_out_dim(x->y, kernel[1], stride[1]) ||
       dy->x != conv_out_dim(x->x, kernel[2], stride[2]))
@@ -350,7 +350,7 @@ extern "C" int rx_conv3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act* 
       for (int c = 0; c < kernel[2]; ++c) {
         RxTap& t = g.taps[g.ntaps];
         t.dz = (int8_t)(a - pz), t.dy = (int8_t)(b - py), t.dx = (int8_t)(c - px);
-        t.w = (uint8_t)g.ntaps;
+        t.w = (uint16_t)g.ntaps;
         ++g.ntaps;
       }
   return wgrad_launch(dt, dy->ptr, x->ptr, dw, g, ws, ws_bytes, (hipStream_t)stream);
@@ -562,7 +562,7 @@ extern "C" int rx_convT3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act*
   RX_RECORD(stream, [=, x_ = RxActV(x), dy_ = RxActV(dy), stride_ = RxI3V(stride)](void* s) { return rx_convT3d_bwd_weight(dt, x_.p(), dy_.p(), dw, stride_.v, ws, ws_bytes, s); });
   if (!rx_act_ok(x) || !rx_act_ok(dy)) RX_FAIL(RX_EINVAL, "rx_convT3d_bwd_weight: bad arguments");
   for (int i = 0; i < 3; ++i)
-    if (stride[i] != 1 && stride[i] != 2) RX_FAIL(RX_EUNSUPPORTED, "rx_convT3d_bwd_weight: strides must be 1 or 2");
+    if (stride[i] < 1 || stride[i] > RX_MAX_STRIDE) RX_FAIL(RX_EUNSUPPORTED, "rx_convT3d_bwd_weight: strides must be 1..%d per axis", RX_MAX_STRIDE);
   if (dy->n != x->n || dy->z != x->z * stride[0] || dy->y != x->y * stride[1] || dy->x != x->x * stride[2])
     RX_FAIL(RX_EINVAL, "rx_convT3d_bwd_weight: geometry mismatch");
   if (ws && dw) {
@@ -585,7 +585,7 @@ extern "C" int rx_convT3d_bwd_weight(rx_dtype dt, const rx_act* x, const rx_act*
       for (int c = 0; c < stride[2]; ++c) {
         RxTap& t = g.taps[g.ntaps];
         t.dz = (int8_t)a, t.dy = (int8_t)b, t.dx = (int8_t)c;
-        t.w = (uint8_t)g.ntaps;
+        t.w = (uint16_t)g.ntaps;
         ++g.ntaps;
       }
   return wgrad_launch(dt, x->ptr, dy->ptr, dw, g, ws, ws_bytes, (hipStream_t)stream);

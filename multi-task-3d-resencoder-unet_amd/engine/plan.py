@@ -179,6 +179,7 @@ class Plan:
         self._gstate: Dict[tuple, dict] = {}
         self._x_static = None
         self._dl_static: Dict[str, torch.Tensor] = {}
+        self._image_t = None                      # channels-last copy of an image with > 16 channels (see _image_act)
         self._build()
 
     def release(self):
@@ -313,18 +314,23 @@ class Plan:
         slope = _slope_of(sp["nonlin"]) if final_slope is None else final_slope
         conv = sp["conv"]
         kernel, stride = self._k3(sp["kernel"]), self._k3(sp["stride"])
+        # any kernel size 1..7 and stride 1..4 per axis (build_network_from_config.py:85-148 hands a manual model_config's values
+        # straight to Conv(k, stride, pad=(k-1)//2)): everything beyond 1 / 3 and 1 / 2 runs on the tap-table gather kernels
         for k in kernel:
-            if k not in (1, 3):
-                raise UnsupportedConfig(f"kernel size {k} has no HIP kernel (1 or 3 per axis)")
+            if not 1 <= k <= 7:
+                raise UnsupportedConfig(f"kernel size {k} has no HIP kernel (1..7 per axis)")
         for s in stride:
-            if s not in (1, 2):
-                raise UnsupportedConfig(f"stride {s} has no HIP kernel (1 or 2 per axis)")
+            if not 1 <= s <= 4:
+                raise UnsupportedConfig(f"stride {s} has no HIP kernel (1..4 per axis)")
         cin, cout = conv.in_channels, conv.out_channels
         cout_p = self._cp(cout)
         first_of_net = first_of_net or x is None      # x is None: the layer reads the NCDHW image (the stem; without one, the first block)
-        if first_of_net and any(s != 1 for s in stride):
-            # a strided first layer (do_stem=False with strides[0] != 1): the first-layer kernels read the image at stride 1 only --
-            # convert the image to the channels-last layout (padded to 32 channels) and run the ordinary strided convolution on it
+        if first_of_net and (any(s != 1 for s in stride) or any(k not in (1, 3) for k in kernel) or cin > 16 or cout_p > 64
+                             or (cin > 4 and cout_p * cin * kernel[0] * kernel[1] * kernel[2] * 4 > 160 * 1024)):
+            # the first-layer kernels read the NCDHW image at stride 1, with 1- / 3-wide kernels, <= 16 input and <= 64 output channels
+            # (weights LDS-resident): anything else (do_stem=False with strides[0] != 1, in_channels 17.., stem_channels > 64, 5- / 7-wide
+            # first kernels) converts the image to the channels-last layout (padded to a multiple of 32 channels) and runs the
+            # ordinary convolution kernels on it
             x = self._image_act(tape)
             first_of_net = False
         in_dims = x.act.dims[1:] if not first_of_net else self.spatial
@@ -340,13 +346,6 @@ class Plan:
         kshape = tuple(conv.weight.shape[2:])
         b_k = self._shadow(conv.bias, (cout_p,), [((slice(0, cout),), (slice(None),))])
         if first_of_net:
-            if cin > 16 or any(s != 1 for s in stride):
-                raise UnsupportedConfig("the first convolution reads the NCDHW image: needs in_channels <= 16, stride 1")
-            if cin > 4 and cout_p * cin * kernel[0] * kernel[1] * kernel[2] * 4 > 160 * 1024:
-                raise UnsupportedConfig(f"the first convolution ({cin} -> {cout} channels, {kernel} kernel) does not fit the LDS of the "
-                                        "first-layer kernels")
-            if cout_p > 64:
-                raise UnsupportedConfig(f"the first convolution writes {cout} channels (its weight-gradient kernel holds <= 64)")
             w_k = self._shadow(conv.weight, (cout_p, cin, *kshape), [((slice(0, cout),), (slice(None),))])
             tape.append(Rec("stem", dict(y=y, w=w_k, b=b_k, widx=widx, bidx=bidx, kernel=kernel)))
         else:
@@ -378,10 +377,17 @@ class Plan:
         if getattr(self, "_image_at", None) is not None:
             return self._image_at
         cin = self.Cin
-        if cin > 16:
-            raise UnsupportedConfig("the first-layer kernels read at most 16 input channels")
         cp = self._cp(cin)
         y = self._new(self.spatial, cp, "image", needs_grad=False)
+        if cin > 16:
+            # more input channels than the first-layer kernels read: a boundary conversion by torch (permute + cast into the persistent
+            # channels-last buffer, whose padding channels stay zero), issued next to the static input copy in run_forward -- outside
+            # any recorded program or captured graph
+            if self.device.type != "meta":
+                y.act.t.zero_()
+            self._image_t = y
+            self._image_at = y
+            return y
         eye = torch.zeros((cp, cin, 1, 1, 1), dtype=torch.float32, device=self.device)
         if self.device.type != "meta":
             eye[torch.arange(cin), torch.arange(cin)] = 1.0
@@ -1266,6 +1272,7 @@ class Plan:
                 self._x_static = torch.empty(self.in_shape, dtype=torch.float32, device=self.device)
             self._x_static.copy_(x)                 # the graph reads a fixed address
             self._x = self._x_static.unsqueeze(2) if self.two_d else self._x_static
+            self._fill_image_t()
             st = self._gstate.get(("f", apply_act))
             capturing = st is not None and st.get("graph") is None and st["calls"] >= 2
             self._graphed(("f", apply_act), lambda: self._forward_body(force_packs=capturing))
@@ -1278,6 +1285,7 @@ class Plan:
                 self._x_static = torch.empty(self.in_shape, dtype=torch.float32, device=self.device)
             self._x_static.copy_(x)                 # the program reads a fixed address
             self._x = self._x_static.unsqueeze(2) if self.two_d else self._x_static
+            self._fill_image_t()
             stale = bool(self._packs_stale())
             dropping = any(g["scale_now"] is not None for g in self._gates) or any(d["active"] for d in self._drops)
             # one program per launch-list VARIANT: with / without the weight re-pack, with / without DropPath factors
@@ -1287,12 +1295,17 @@ class Plan:
                 self._mark_packs_fresh()
         else:
             self._x = x.unsqueeze(2) if self.two_d else x
+            self._fill_image_t()
             self._forward_body(force_packs=False)
         self.generation += 1
         outs = {}
         for k, v in self.outputs.items():
             outs[k] = v.squeeze(2) if self.two_d else v
         return outs
+
+    def _fill_image_t(self):
+        if self._image_t is not None:
+            self._image_t.act.t[..., :self.Cin].copy_(self._x.permute(0, 2, 3, 4, 1))
 
     def _backward_body(self):
         self._dy_free.clear()       # the previous backward ended with the side stream joined: nothing is still read

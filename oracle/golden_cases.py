@@ -124,6 +124,26 @@ CASES = {
                      full_grads=("stages.0.blocks.0.conv1.conv.weight", "stages.0.blocks.0.skip.0.conv.weight",
                                  "stages.1.blocks.1.conv2.conv.weight", "seg.transpconvs.1.weight",
                                  "seg.stages.1.blocks.0.conv1.conv.weight")),
+    # ---- round 3: the conv geometries and widths the engine used to refuse (VERDICT r2 "What's missing" #2, #3) ----------------
+    # 5- / 7-wide kernels and strides 3 / 4, per stage, by hand (build_network_from_config.py:85-148 -> Conv(k, stride, pad=(k-1)//2)):
+    # 24^3 -> stride 3 -> 8^3 -> stride 2 -> 4^3; AvgPool(3) / AvgPool(2) skip paths, ConvTranspose k = s = 2 and 3 in the decoder
+    "big_kernels": dict(patch=(24, 24, 24), batch=2, in_channels=1, tasks=TASKS_SIGMOID_SHEET, autoconfigure=False,
+                        model_config=_manual(features_per_stage=[32, 32, 64], kernel_sizes=[[5, 5, 5], [3, 3, 3], [7, 7, 7]],
+                                             strides=[[1, 1, 1], [3, 3, 3], [2, 2, 2]]),
+                        seed=11, data_seed=1, train=True,
+                        full_grads=("stages.1.blocks.0.conv1.conv.weight", "sheet.transpconvs.1.weight", "sheet.transpconvs.0.weight")),
+    # stride 4 with a (1, 4, 4) anisotropic step and mixed kernel sizes per axis, plain-conv encoder, ResidualBlock decoder
+    "stride4_mixed": dict(patch=(8, 32, 32), batch=2, in_channels=2, tasks=TASKS_SOFTMAX2_W1, autoconfigure=False,
+                          model_config=_manual(features_per_stage=[32, 64], num_stages=2, n_blocks_per_stage=[1, 2],
+                                               n_conv_per_stage_decoder=[1], kernel_sizes=[[3, 5, 5], [1, 7, 3]],
+                                               strides=[[1, 1, 1], [1, 4, 4]], basic_decoder_block="ResidualBlock"),
+                          seed=11, data_seed=1, train=True,
+                          full_grads=("stages.1.blocks.0.conv1.conv.weight", "seg.transpconvs.0.weight")),
+    # 20 input channels (the first-layer kernels read <= 16) into a 96-channel stem (their weight gradient holds <= 64)
+    "wide_in_stem": dict(patch=(16, 16, 16), batch=2, in_channels=20, tasks=TASKS_SIGMOID_SHEET, autoconfigure=False,
+                         model_config=_manual(stem_channels=96), seed=11, data_seed=1, train=True,
+                         full_grads=("stages.0.blocks.0.conv1.conv.weight", "stages.0.blocks.0.skip.0.conv.weight",
+                                     "sheet.transpconvs.1.weight")),
 }
 
 # Cases WITHOUT a reference fixture -- PARITY UNPINNED: SqueezeExcite / DropPath live in the un-vendored

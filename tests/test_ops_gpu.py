@@ -60,6 +60,16 @@ CONV_CASES = [
     (128, 64, (32, 32, 64), (3, 3, 3), (2, 2, 2)),    # stride-2 data gradient on the parity-class halo kernel (64 dY channels)
     (128, 64, (24, 40, 72), (3, 3, 3), (2, 2, 2)),    # same, ragged dY tiles
     (64, 128, (12, 20, 18), (1, 1, 1), (1, 1, 1)),    # 1x1x1 projection above 4096 voxels: the streaming pointwise kernel (fwd and bwd-data)
+    # round 3: any kernel size 1..7 / stride 1..4 per axis (the reference passes a manual model_config's values straight to
+    # Conv(k, stride, pad=(k-1)//2), build_network_from_config.py:85-148) -- tap tables of up to 343 entries
+    (32, 32, (9, 10, 12), (5, 5, 5), (1, 1, 1)),      # 125 taps
+    (32, 64, (7, 9, 11), (7, 7, 7), (1, 1, 1)),       # 343 taps: the table limit; weights beyond the 27-tap pack tile
+    (32, 32, (6, 12, 13), (1, 5, 7), (1, 2, 1)),      # mixed sizes, one strided axis
+    (64, 32, (12, 12, 12), (3, 3, 3), (3, 3, 3)),     # stride 3: 27 output parity classes in the data gradient (4 launches of <= 8)
+    (32, 32, (16, 16, 16), (5, 5, 5), (4, 4, 4)),     # stride 4, 5-wide kernel: 64 classes
+    (32, 32, (9, 9, 12), (7, 3, 5), (2, 1, 3)),       # everything different
+    (32, 32, (8, 9, 10), (2, 4, 6), (1, 2, 2)),       # even kernel sizes: pad (k-1)//2 is asymmetric, the output shrinks
+    (32, 32, (8, 8, 8), (1, 1, 1), (2, 2, 2)),        # kernel narrower than the stride: 7 of the 8 classes of dx have no tap (zeros)
 ]
 
 
@@ -138,6 +148,9 @@ CONVT_CASES = [
     (64, 32, (16, 32, 40), (2, 2, 2)),         # >= 32768 coarse voxels: convT_wgrad_kernel (every operand byte once)
     (128, 64, (16, 32, 34), (2, 2, 2)),        # the same on the 4 x 2 block instantiation (80 KB of LDS panels)
     (64, 64, (20, 32, 32), (1, 2, 2)),         # four taps: waves 4..7 of the weight-gradient workgroup only stage
+    (64, 32, (5, 6, 7), (3, 3, 3)),            # round 3: stride 3 (27 phases: four launches of <= 8) and 4
+    (32, 32, (4, 5, 6), (1, 4, 3)),
+    (64, 64, (8, 10, 12), (4, 4, 4)),          # 64 taps: pointwise weights would not fit -> gather kernel; naive pack (> 27 taps)
 ]
 
 
@@ -257,9 +270,9 @@ def test_channel_dropout_as_masked_statistics(ops, dtype, c, dims):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("s", [(2, 2, 2), (1, 2, 2)])
+@pytest.mark.parametrize("s", [(2, 2, 2), (1, 2, 2), (3, 3, 3), (1, 4, 2)])
 def test_avgpool(ops, dtype, s):
-    n, c, dims = 2, 64, (4, 6, 8)
+    n, c, dims = 2, 64, (4, 6, 8) if max(s) <= 2 else (12, 12, 24)
     x = rnd((n, c, *dims), dtype, 12)
     xr = x.clone().requires_grad_(True)
     ref = F.avg_pool3d(xr, s, s)

@@ -88,10 +88,11 @@ def test_unsupported_configs_fail_loudly(NetworkFromConfig):
     with pytest.raises((UnsupportedConfig, ValueError, KeyError, AttributeError, TypeError)):
         net = NetworkFromConfig(mgr).cuda()
         net(torch.zeros(1, 1, 16, 16, 16, device="cuda"))
-    mgr = oracle.make_mgr((16, 16, 16), ONE, 17, 1, True, {})                              # (up to 16 input channels run)
+    # (round 3: any in_channels, 5- / 7-wide kernels and strides 3 / 4 run -- goldens wide_in_stem, big_kernels, stride4_mixed)
+    mgr = oracle.make_mgr((16, 16, 16), ONE, 1, 1, False, manual(kernel_sizes=[[9, 3, 3], [3, 3, 3], [3, 3, 3]]))
     net = NetworkFromConfig(mgr).cuda()
-    with pytest.raises(UnsupportedConfig):
-        net(torch.zeros(1, 17, 16, 16, 16, device="cuda"))
+    with pytest.raises(UnsupportedConfig):                                                  # kernels wider than 7 have no tap table
+        net(torch.zeros(1, 1, 16, 16, 16, device="cuda"))
 
 
 def test_droppath_training_and_eval(NetworkFromConfig):
