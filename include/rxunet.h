@@ -219,7 +219,8 @@ int rx_head_bwd(rx_dtype dt, const float* dout_ncdhw, const rx_act* x, const flo
                 float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
 
 /* InstanceNorm apply + LeakyReLU of the layer under a task head AND the head's 1x1x1 conv (+ eval-mode activation) in one pass:
- * the activated output is written (skip of nothing, but the backward needs it) and not re-read.  Same `out` bit for bit and the same
+ * the activated output is written and not re-read -- or, with out = NULL, not written at all (nobody but the head reads that
+ * layer's output, and rx_instnorm_act_bwd_head rebuilds what the backward needs from y).  Same `out` bit for bit and the same
  * logits to fp32 round-off as rx_instnorm_act_fwd followed by rx_head_fwd (decoder.py:115-131,151-152).  16-bit types, k <= 4. */
 int rx_instnorm_act_head_fwd(rx_dtype dt, const rx_act* y, const float* stats, const rx_act* out, float slope,
                              const float* head_w, const float* head_b, int k, float* out_ncdhw, int act, void* stream);
@@ -227,9 +228,14 @@ int rx_instnorm_act_head_fwd(rx_dtype dt, const rx_act* y, const float* stats, c
 /* InstanceNorm + LeakyReLU backward of the layer that feeds a task head (the conv block of the last decoder stage,
  * decoder.py:115-131: no residual), with the head's data gradient formed on the fly: g[v][c] = sum_k dout[k][v] * w[k][c] is
  * never written (call rx_head_bwd with dx = NULL for dw / db).  Same dy, bit for bit, as rx_head_bwd(dx = g) followed by
- * rx_instnorm_act_bwd(g, y, stats, out = NULL, ...).  k <= 4; ws as for rx_instnorm_act_bwd. */
+ * rx_instnorm_act_bwd(g, y, stats, out = NULL, ...).  k <= 4; ws as for rx_instnorm_act_bwd.
+ * head_dw (k, C) / head_db (k), optional and together (round 3): the head's OWN parameter gradients out of the same reduce pass,
+ * dw[k][c] = sum dout[k][v] * lrelu(xhat)[v][c] with the activation recomputed from y and rounded as the forward stored it --
+ * rx_head_bwd is then not called and rx_instnorm_act_head_fwd may be given out = NULL (the activated output of that layer, 268 MB
+ * at cfg2, is neither written nor read). */
 int rx_instnorm_act_bwd_head(rx_dtype dt, const float* dout_ncdhw, int k, const float* head_w, const rx_act* y,
-                             const float* stats, float slope, const rx_act* dy, void* ws, size_t ws_bytes, void* stream);
+                             const float* stats, float slope, const rx_act* dy, float* head_dw, float* head_db, void* ws,
+                             size_t ws_bytes, void* stream);
 
 /* ---- per-channel sum over (n, voxels): bias gradients ----------------------------------- */
 size_t rx_channel_sum_workspace(const rx_act* x);

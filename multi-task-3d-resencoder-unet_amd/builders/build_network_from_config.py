@@ -168,6 +168,8 @@ class NetworkFromConfig(nn.Module):
 
         cd = model_config.get("compute_dtype", None)
         self.compute_dtype = _DTYPES[cd] if isinstance(cd, str) else cd   # None -> follow autocast
+        import weakref
+        object.__setattr__(self.shared_encoder, "_owner", weakref.ref(self))     # (not a submodule link: feature extraction hook)
         self._plans = {}
         self._weights_epoch = 0     # advanced by every backward: fused optimizers do not bump Tensor._version (engine/plan.py)
         if getattr(mgr, "verbose", False):
@@ -217,6 +219,15 @@ class NetworkFromConfig(nn.Module):
             return outs
         outs = plan.run_forward(x, apply_act=not self.training)
         return {n: outs[n].clone() for n in names}
+
+    @torch.compiler.disable(recursive=True)
+    def encode(self, x):
+        """the shared encoder alone (reference encoder.py:148-158, `model.shared_encoder(x)`): per-stage outputs as NCDHW fp32
+        tensors, computed by the encoder part of an inference plan (no autograd)."""
+        self._check_input(x)
+        with torch.no_grad():
+            plan = self.plan_for(x.shape, self._resolve_dtype(), x.device, False)
+            return plan.run_encoder(x)
 
     def _check_input(self, x):
         if not x.is_cuda:

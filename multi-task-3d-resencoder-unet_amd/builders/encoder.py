@@ -80,6 +80,17 @@ class Encoder(EngineOnly):
         self.conv_bias = conv_bias
         self.kernel_sizes = kernel_sizes
 
+    def forward(self, x):
+        """feature extraction through the engine, as `model.shared_encoder(x)` does upstream (encoder.py:148-158): the list of
+        per-stage outputs (NCDHW, fp32) -- or only the last one without `return_skips`.  Runs the encoder part of the owning
+        network's plan on the HIP kernels, WITHOUT autograd (the training path goes through the whole network: one engine call
+        owns forward and backward); a container that is not part of a NetworkFromConfig has nothing to run on."""
+        owner = self._owner() if getattr(self, "_owner", None) is not None else None
+        if owner is None:
+            return super().forward(x)
+        skips = owner.encode(x)
+        return skips if self.return_skips else skips[-1]
+
     def compute_conv_feature_map_size(self, input_size):
         out = self.stem.compute_conv_feature_map_size(input_size) if self.stem is not None else np.int64(0)
         for s in range(len(self.stages)):

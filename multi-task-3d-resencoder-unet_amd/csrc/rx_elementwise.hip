@@ -1387,7 +1387,7 @@ __global__ __launch_bounds__(256) void in_act_head_fwd_kernel(const T* __restric
 #pragma unroll
   for (int k = 0; k < RX_HEADG_MAXK; ++k) b[k] = k < K ? hb[k] : 0.f;
   const T* yn = y + n * sy;
-  T* on = out + n * so;
+  T* on = out ? out + n * so : nullptr;
   for (; i < total; i += step) {
     long v = i / CV;
     Vec16<T> a = ld16(yn + v * ldy + cv * P);
@@ -1400,7 +1400,7 @@ __global__ __launch_bounds__(256) void in_act_head_fwd_kernel(const T* __restric
       o.v[j] = Elem<T>::from_f(f);
       of[j] = Elem<T>::to_f(o.v[j]);
     }
-    st16(on + v * ldo + cv * P, o);
+    if (on) st16(on + v * ldo + cv * P, o);      // (out == NULL: nobody reads the activated output -- see rx_instnorm_act_bwd_head's dw / db)
     // The CV lanes of a voxel each form the partial dot products of THEIR 8 channels, then hand a running sum along in channel
     // order (lane cv adds its partial to what lane cv-1 holds).  No divergent region between the cross-lane moves: every lane
     // computes, a select keeps the owner's value.  (The first version did the adds inside `if (cv == s)`; with a SECOND process
@@ -1457,8 +1457,8 @@ extern "C" int rx_instnorm_act_head_fwd(rx_dtype dt, const rx_act* y, const floa
   RX_RECORD(stream, [=, y_ = RxActV(y), out_ = RxActV(out)](void* s) { return rx_instnorm_act_head_fwd(dt, y_.p(), stats, out_.p(), slope, head_w, head_b, k, out_ncdhw, act, s); });
   int rc = check_vec_channels(y, dt, "rx_instnorm_act_head_fwd(y)");
   if (rc) return rc;
-  if ((rc = check_vec_channels(out, dt, "rx_instnorm_act_head_fwd(out)"))) return rc;
-  if (!stats || !head_w || !head_b || !out_ncdhw || !same_geom(y, out)) RX_FAIL(RX_EINVAL, "rx_instnorm_act_head_fwd: bad arguments");
+  if (out && (rc = check_vec_channels(out, dt, "rx_instnorm_act_head_fwd(out)"))) return rc;
+  if (!stats || !head_w || !head_b || !out_ncdhw || (out && !same_geom(y, out))) RX_FAIL(RX_EINVAL, "rx_instnorm_act_head_fwd: bad arguments");
   if (dt == RX_F32 || k < 1 || k > RX_HEADG_MAXK || 64 % (y->c / 8) != 0)
     RX_FAIL(RX_EUNSUPPORTED, "rx_instnorm_act_head_fwd: 16-bit types, K <= %d, C / 8 dividing 64", RX_HEADG_MAXK);
   const long V = rx_act_voxels(y);
@@ -1468,7 +1468,8 @@ extern "C" int rx_instnorm_act_head_fwd(rx_dtype dt, const rx_act* y, const floa
     int CV = y->c / P;
     int G = sweep_grid(V * CV, CV);
     hipLaunchKernelGGL((in_act_head_fwd_kernel<T>), dim3(G, y->n), dim3(256), 0, st, (const T*)y->ptr, y->ld, V * y->ld, stats,
-                       (T*)out->ptr, out->ld, V * out->ld, (int)V, y->c, slope, head_w, head_b, k, out_ncdhw, act);
+                       out ? (T*)out->ptr : (T*)nullptr, out ? out->ld : 0, out ? V * out->ld : 0L, (int)V, y->c, slope, head_w, head_b, k,
+                       out_ncdhw, act);
   });
   RX_CHECK_LAUNCH("rx_instnorm_act_head_fwd");
   return RX_OK;
@@ -1480,7 +1481,12 @@ extern "C" int rx_instnorm_act_head_fwd(rx_dtype dt, const rx_act* y, const floa
 // passes of the InstanceNorm backward then read back twice.  Here both passes rebuild g from the fp32 logit gradient (4*K bytes
 // per voxel instead of 2*C) and the head's weights; rx_head_bwd is called with dx = NULL and only reduces dw / db.  g is
 // rounded to the storage type exactly where rx_head_bwd rounded it, so dy is bit-identical to the three-tensor path.
-template <typename T>
+// KW > 0 (round 3): the same pass also reduces the HEAD's parameter gradients, dw[k][c] = sum_v dout[k][v] * a[v][c] and db[k] =
+// sum_v dout[k][v], with a = lrelu(xhat) recomputed from y and rounded to the storage type as the forward stored it -- the
+// activated output of the layer under a head (268 MB at cfg2) is then neither written by the forward nor read by rx_head_bwd
+// (a 131 us launch at cfg2), which is not called at all.  Accumulators 2 .. 2+K-1 hold dw, accumulator 2+K holds db[k] in lane k
+// (only the threads of channel vector 0 add to it: every channel vector of a voxel sees the same dout).
+template <typename T, int KW = 0>
 struct InBwdHeadOp {
   ActView<T> y;
   const float* stats;
@@ -1499,19 +1505,21 @@ struct InBwdHeadOp {
       for (int k = 0; k < RX_HEADG_MAXK; ++k) w[k][j] = k < K ? hw[k * C + c0 + j] : 0.f;
     }
   }
-  __device__ inline void accumulate(int n, int v, int c0, float (&acc)[2][Elem<T>::PER16]) const {
+  __device__ inline void accumulate(int n, int v, int c0, float (&acc)[KW ? KW + 3 : 2][Elem<T>::PER16]) const {
     constexpr int P = Elem<T>::PER16;
     Vec16<T> yv = ld16(y.at(n, v, c0));
-    float d[P];
+    float d[P], gk[RX_HEADG_MAXK];
 #pragma unroll
     for (int j = 0; j < P; ++j) d[j] = 0.f;
 #pragma unroll
-    for (int k = 0; k < RX_HEADG_MAXK; ++k)
+    for (int k = 0; k < RX_HEADG_MAXK; ++k) {
+      gk[k] = 0.f;
       if (k < K) {
-        const float gk = dout[((size_t)n * K + k) * V + v];
+        gk[k] = dout[((size_t)n * K + k) * V + v];
 #pragma unroll
-        for (int j = 0; j < P; ++j) d[j] += gk * w[k][j];
+        for (int j = 0; j < P; ++j) d[j] += gk[k] * w[k][j];
       }
+    }
 #pragma unroll
     for (int j = 0; j < P; ++j) {
       float gg = Elem<T>::to_f(Elem<T>::from_f(d[j]));
@@ -1519,9 +1527,41 @@ struct InBwdHeadOp {
       if (mask_xhat && !(xh > 0.f)) gg *= slope;
       acc[0][j] += gg;
       acc[1][j] += gg * xh;
+      if (KW) {
+        const float a = Elem<T>::to_f(Elem<T>::from_f(xh > 0.f ? xh : xh * slope));      // what rx_instnorm_act_head_fwd stored
+#pragma unroll
+        for (int k = 0; k < KW; ++k) acc[2 + k][j] += gk[k] * a;
+      }
+    }
+    if (KW && c0 == 0) {
+#pragma unroll
+      for (int k = 0; k < KW; ++k) acc[2 + KW][k] += gk[k];
     }
   }
 };
+
+// finalize of the pass above: m12[n][c] (both means), dw[k][c] and db[k] (sums over n and chunks), one workgroup per output
+__global__ __launch_bounds__(256) void inbwd_head_finalize(const float* __restrict__ partial, int N, int nchunks, int nacc, int C, int K, double V,
+                                                           float* __restrict__ m12, float* __restrict__ dw, float* __restrict__ db) {
+  const int i = blockIdx.x;
+  double s0 = 0.0, s1 = 0.0;
+  if (i < N * C) {
+    const int n = i / C, c = i - n * C;
+    fin_gather(partial + ((size_t)n * nchunks * nacc) * C + c, (size_t)nacc * C, nchunks, C, s0, s1);
+    if (threadIdx.x == 0) m12[2 * i] = (float)(s0 / V), m12[2 * i + 1] = (float)(s1 / V);
+    return;
+  }
+  const int j = i - N * C;
+  if (j < K * C) {
+    const int k = j / C, c = j - k * C;
+    fin_gather(partial + (size_t)(2 + k) * C + c, (size_t)nacc * C, N * nchunks, 0, s0, s1);
+    if (threadIdx.x == 0) dw[j] = (float)s0;
+    return;
+  }
+  const int k = j - K * C;
+  fin_gather(partial + (size_t)(2 + K) * C + k, (size_t)nacc * C, N * nchunks, 0, s0, s1);
+  if (threadIdx.x == 0) db[k] = (float)s0;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void in_act_bwd_apply_head_kernel(const float* __restrict__ dout, int K, const float* __restrict__ hw,
@@ -1575,9 +1615,16 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_head_kernel(const float*
 // dy = InstanceNorm+LeakyReLU backward of a layer WITHOUT residual whose output gradient is the data gradient of a 1x1x1 head:
 // g = dout (N,K,Z,Y,X fp32) x head_w (K,C), never materialised.  Same result as rx_head_bwd(dx = g) + rx_instnorm_act_bwd(g, ...,
 // out = NULL).  K <= 4.
+#define RX_HEAD_REDUCE(KW_)                                                                                                              \
+  do {                                                                                                                                   \
+    InBwdHeadOp<T, KW_> op{make_view<T>(y), stats, dout_ncdhw, head_w, C, k, (int)V, slope, mask_xhat, {}, {}, {}};                       \
+    hipLaunchKernelGGL((colreduce_kernel<T, (KW_ ? KW_ + 3 : 2), InBwdHeadOp<T, KW_>>), dim3(p.nchunks, N), dim3(256), lds, st, op, (int)V, C, \
+                       p.chunk_vox, partial);                                                                                            \
+  } while (0)
 extern "C" int rx_instnorm_act_bwd_head(rx_dtype dt, const float* dout_ncdhw, int k, const float* head_w, const rx_act* y,
-                                        const float* stats, float slope, const rx_act* dy, void* ws, size_t ws_bytes, void* stream) {
-  RX_RECORD(stream, [=, y_ = RxActV(y), dy_ = RxActV(dy)](void* s) { return rx_instnorm_act_bwd_head(dt, dout_ncdhw, k, head_w, y_.p(), stats, slope, dy_.p(), ws, ws_bytes, s); });
+                                        const float* stats, float slope, const rx_act* dy, float* head_dw, float* head_db, void* ws,
+                                        size_t ws_bytes, void* stream) {
+  RX_RECORD(stream, [=, y_ = RxActV(y), dy_ = RxActV(dy)](void* s) { return rx_instnorm_act_bwd_head(dt, dout_ncdhw, k, head_w, y_.p(), stats, slope, dy_.p(), head_dw, head_db, ws, ws_bytes, s); });
   int rc;
   if ((rc = check_vec_channels(y, dt, "rx_instnorm_act_bwd_head(y)"))) return rc;
   if ((rc = check_vec_channels(dy, dt, "rx_instnorm_act_bwd_head(dy)"))) return rc;
@@ -1586,22 +1633,30 @@ extern "C" int rx_instnorm_act_bwd_head(rx_dtype dt, const float* dout_ncdhw, in
   const long V = rx_act_voxels(y);
   const int N = y->n, C = y->c;
   if (V > 0x7fffffffL) RX_FAIL(RX_EUNSUPPORTED, "rx_instnorm_act_bwd_head: volume too large");
-  size_t need = rx_reduce_ws_bytes(N, V, C, 2) + (size_t)N * C * 2 * sizeof(float);
+  if ((head_dw == nullptr) != (head_db == nullptr)) RX_FAIL(RX_EINVAL, "rx_instnorm_act_bwd_head: head_dw and head_db come together");
+  const int nacc = head_dw ? k + 3 : 2;
+  size_t need = rx_reduce_ws_bytes(N, V, C, nacc) + (size_t)N * C * 2 * sizeof(float);
   if (ws_bytes < need) RX_FAIL(RX_EWORKSPACE, "rx_instnorm_act_bwd_head: workspace too small (%zu < %zu)", ws_bytes, need);
   float* partial = (float*)ws;
-  float* m12 = (float*)((char*)ws + rx_align_up(rx_reduce_ws_bytes(N, V, C, 2) - 256, 256));
+  float* m12 = (float*)((char*)ws + rx_align_up(rx_reduce_ws_bytes(N, V, C, nacc) - 256, 256));
   hipStream_t st = (hipStream_t)stream;
   const bool mask_xhat = slope != 1.0f;
   RX_DISPATCH_DTYPE(dt, T, {
     constexpr int P = Elem<T>::PER16;
     ReducePlan p = rx_reduce_plan(V, C, P);
     int CV = C / P, VP = 256 / CV;
-    InBwdHeadOp<T> op{make_view<T>(y), stats, dout_ncdhw, head_w, C, k, (int)V, slope, mask_xhat, {}, {}, {}};
-    size_t lds = (size_t)2 * (VP > 4 ? VP : 4) * C * sizeof(float);
-    hipLaunchKernelGGL((colreduce_kernel<T, 2, InBwdHeadOp<T>>), dim3(p.nchunks, N), dim3(256), lds, st, op, (int)V, C, p.chunk_vox,
-                       partial);
-    fin_launch(st, (const float*)partial, N, p.nchunks, 2, C,
-                       (double)V, 0.f, (int)FIN_MEAN2, m12);
+    size_t lds = (size_t)nacc * (VP > 4 ? VP : 4) * C * sizeof(float);
+    if (!head_dw) {
+      RX_HEAD_REDUCE(0);
+      fin_launch(st, (const float*)partial, N, p.nchunks, 2, C, (double)V, 0.f, (int)FIN_MEAN2, m12);
+    } else {
+      if (k == 1) RX_HEAD_REDUCE(1);
+      else if (k == 2) RX_HEAD_REDUCE(2);
+      else if (k == 3) RX_HEAD_REDUCE(3);
+      else RX_HEAD_REDUCE(4);
+      hipLaunchKernelGGL(inbwd_head_finalize, dim3(N * C + k * C + k), dim3(256), 0, st, (const float*)partial, N, p.nchunks, nacc, C, k,
+                         (double)V, m12, head_dw, head_db);
+    }
     int G = sweep_grid(V * CV, CV);
     hipLaunchKernelGGL((in_act_bwd_apply_head_kernel<T>), dim3(G, N), dim3(256), 0, st, dout_ncdhw, k, head_w, (const T*)y->ptr, y->ld,
                        V * y->ld, stats, (const float*)m12, (T*)dy->ptr, dy->ld, V * dy->ld, (int)V, C, slope, mask_xhat ? 1 : 0);
@@ -1609,6 +1664,7 @@ extern "C" int rx_instnorm_act_bwd_head(rx_dtype dt, const float* dout_ncdhw, in
   RX_CHECK_LAUNCH("rx_instnorm_act_bwd_head");
   return RX_OK;
 }
+#undef RX_HEAD_REDUCE
 
 // ---- stem convolution on the NCDHW fp32 image (Cin <= 16; the MFMA variants of rx_stem_wgrad.hip take Cin <= 4) ----------
 // thread -> (voxel, vector of P output channels); weights in LDS as [tap*Cin][Cout]

@@ -83,7 +83,8 @@ _SIGNATURES = {
     "rx_head_fwd": (c_int, [c_int, _P, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "rx_head_bwd_workspace": (c_size_t, [_P, c_int]),
     "rx_instnorm_act_head_fwd": (c_int, [c_int, _P, c_void_p, _P, c_float, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
-    "rx_instnorm_act_bwd_head": (c_int, [c_int, c_void_p, c_int, c_void_p, _P, c_void_p, c_float, _P, c_void_p, c_size_t, c_void_p]),
+    "rx_instnorm_act_bwd_head": (c_int, [c_int, c_void_p, c_int, c_void_p, _P, c_void_p, c_float, _P, c_void_p, c_void_p, c_void_p, c_size_t,
+                                         c_void_p]),
     "rx_grad_norm_clip_partials": (ctypes.c_long, [c_int, c_void_p]),
     "rx_grad_norm_clip": (c_int, [c_int, c_void_p, c_void_p, c_float, c_void_p, ctypes.c_long, c_void_p, c_void_p]),
     "rx_head_bwd": (c_int, [c_int, c_void_p, _P, c_void_p, c_int, _P, c_void_p, c_void_p, c_void_p, c_size_t,

@@ -551,16 +551,20 @@ def head_bwd(dout_ncdhw, x, w, dx, dw, db, ws=None):
 
 def instnorm_act_head_fwd(y, stats, out, w, b, out_ncdhw, act, slope=0.01):
     """InstanceNorm apply + LeakyReLU + the task head's 1x1x1 conv (+ eval activation) in one pass over y"""
-    check(load().rx_instnorm_act_head_fwd(_code(y.dtype), byref(y.desc()), _ptr(stats), byref(out.desc()), float(slope), _ptr(w), _ptr(b),
-                                          w.shape[0], _ptr(out_ncdhw), int(act), stream_ptr()), "rx_instnorm_act_head_fwd")
+    check(load().rx_instnorm_act_head_fwd(_code(y.dtype), byref(y.desc()), _ptr(stats), byref(out.desc()) if out is not None else None,
+                                          float(slope), _ptr(w), _ptr(b), w.shape[0], _ptr(out_ncdhw), int(act), stream_ptr()),
+          "rx_instnorm_act_head_fwd")
 
 
-def instnorm_act_bwd_head(dout_ncdhw, w, y, stats, dy, slope=0.01, ws=None):
-    """InstanceNorm + LeakyReLU backward of the layer under a task head; the head's data gradient dout x w is formed on the fly
-    (head_bwd is then called with dx=None)"""
+def instnorm_act_bwd_head(dout_ncdhw, w, y, stats, dy, slope=0.01, ws=None, dw=None, db=None):
+    """InstanceNorm + LeakyReLU backward of the layer under a task head; the head's data gradient dout x w is formed on the fly.
+    dw / db (optional, together): the head's own parameter gradients out of the same reduce pass (the activation is recomputed
+    from y) -- head_bwd is then not called at all and the forward need not store the activated output; without them head_bwd is
+    called with dx=None"""
     ws = workspace() if ws is None else ws
     check(load().rx_instnorm_act_bwd_head(_code(y.dtype), _ptr(dout_ncdhw), w.shape[0], _ptr(w), byref(y.desc()), _ptr(stats),
-                                          float(slope), byref(dy.desc()), *_ws_args(ws), stream_ptr()), "rx_instnorm_act_bwd_head")
+                                          float(slope), byref(dy.desc()), _ptr(dw), _ptr(db), *_ws_args(ws), stream_ptr()),
+          "rx_instnorm_act_bwd_head")
 
 
 def channel_sum(x, out, ws=None):
@@ -674,7 +678,7 @@ head_fwd = _hbm("head_fwd", lambda x, w, b, out_ncdhw, act=0: _tb(x) + out_ncdhw
 head_bwd = _hbm("head_bwd", lambda dout_ncdhw, x, w, dx, dw, db, ws=None: dout_ncdhw.numel() * 4 + _tb(x) + _tb(dx))(head_bwd)
 instnorm_act_head_fwd = _hbm("in_act_head_fwd", lambda y, stats, out, w, b, out_ncdhw, act, slope=0.01:
                              _tb(y) + _tb(out) + out_ncdhw.numel() * 4)(instnorm_act_head_fwd)
-instnorm_act_bwd_head = _hbm("in_act_bwd_head(colreduce+apply)", lambda dout_ncdhw, w, y, stats, dy, slope=0.01, ws=None:
+instnorm_act_bwd_head = _hbm("in_act_bwd_head(colreduce+apply)", lambda dout_ncdhw, w, y, stats, dy, slope=0.01, ws=None, dw=None, db=None:
                              dout_ncdhw.numel() * 4 + _tb(y) + _tb(dy))(instnorm_act_bwd_head)
 channel_sum = _hbm("channel_sum", lambda x, out, ws=None: _tb(x))(channel_sum)
 pack_conv_weight = _hbm("pack", _pack_bytes)(pack_conv_weight)

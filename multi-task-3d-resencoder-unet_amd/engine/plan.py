@@ -551,6 +551,7 @@ class Plan:
                 for mi, m in enumerate(mods):
                     h = self._emit_cdnr(tape, m, h, out=home if mi == len(mods) - 1 else None)
             skips.append(h)
+        self.enc_skips = [(at, feats[i]) for i, at in enumerate(skips)]      # (activation, real channel count) per stage
 
         # ---- decoders
         self.head_recs = []
@@ -616,7 +617,10 @@ class Plan:
     def _gen_forward(self):
         P = self
         f = self.fwd
+        self.n_fwd_enc = None                 # number of forward steps that belong to the encoder tape (run_encoder)
         for tape in [self.enc_tape] + self.dec_tapes:
+            if tape is not self.enc_tape and self.n_fwd_enc is None:
+                self.n_fwd_enc = len(f)
             # conv -> InstanceNorm pairs whose statistics can come out of the conv epilogue (rx_conv3d_fwd_stats): 3x3x3
             # stride-1 layers in a 16-bit compute type, above the size the single-launch InstanceNorm kernel takes
             for i, rec in enumerate(tape[:-1]):
@@ -695,8 +699,11 @@ class Plan:
                             if not a.get("stats_done"):
                                 ops.instnorm_stats(a["y"].act, a["stats"], P._eps_now(a))
                                 P._mask_dropped(a)
-                            ops.instnorm_act_head_fwd(a["y"].act, a["stats"], a["out"].act, head["w"].view(head["k"], -1), head["b"],
-                                                      head["out"], head["act"] if P._apply_act else _l.RX_ACT_NONE, a["slope"])
+                            # the activated output is stored only if somebody will read it: a training plan whose backward
+                            # rebuilds the head's gradients from y (a["head_src"], set by _gen_backward) and an inference plan do not
+                            keep = P.needs_grad and not a.get("head_dw_fused")
+                            ops.instnorm_act_head_fwd(a["y"].act, a["stats"], a["out"].act if keep else None, head["w"].view(head["k"], -1),
+                                                      head["b"], head["out"], head["act"] if P._apply_act else _l.RX_ACT_NONE, a["slope"])
                             return
                         pool = a.get("pool_to")
                         if pool is not None:
@@ -843,6 +850,8 @@ class Plan:
                                     new_grad(i).zero_()
                                     done(i)
                             return
+                        if hinfo.get("dw_fused"):     # dw / db come out of the InstanceNorm backward's reduce pass (next step)
+                            return
                         dw, db = new_grad(a["widx"]), new_grad(a["bidx"])
                         ops.head_bwd(dl, a["x"].act, a["w"].view(a["k"], -1), None if hinfo["fused"] else gx, dw, db)
                         done(a["widx"])
@@ -871,6 +880,13 @@ class Plan:
                         if len(heads) == 1 and heads[0]["k"] <= 4:
                             a["head_src"] = heads[0]
                             gw[1]["fused"] = True
+                            # ... and the head's own dw / db from the same reduce pass (the activation is recomputed from y): no
+                            # head_bwd launch, and the forward does not store this layer's activated output at all.  Needs the
+                            # forward's fused head (the un-fused head kernel reads the stored output) and an un-padded head weight.
+                            if (heads[0].get("fwd_fused") and heads[0]["w"] is self.params[heads[0]["widx"]]
+                                    and os.environ.get("RX_FUSED_HEAD_DW", "1") != "0"):
+                                a["head_dw_fused"] = True
+                                gw[1]["dw_fused"] = True
                     if (gw[0] == "conv" and a["gate"] is None and res is None and self.dtype != torch.float32
                             and out.act.full_buffer and out.act.root is None and out.act.c == 32 and out.act.voxels > 512
                             and out.act.dims[3] >= 16 and os.environ.get("RX_FUSED_BWD_STATS", "1") != "0"):
@@ -926,7 +942,13 @@ class Plan:
                         mask_out = a["out"].act if (a["slope"] != 1.0 and a["res"] is not None) else None
                         hs = a.get("head_src")
                         dl = P._dlogits.get(hs["name"]) if hs is not None else None   # None: task outside the loss, gout was zeroed
-                        if dl is not None:
+                        if dl is not None and a.get("head_dw_fused"):
+                            dw, db = new_grad(hs["widx"]), new_grad(hs["bidx"])
+                            ops.instnorm_act_bwd_head(dl, hs["w"].view(hs["k"], -1), a["y"].act, a["stats"], dy, a["slope"],
+                                                      dw=dw.view(hs["k"], -1), db=db)
+                            done(hs["widx"])
+                            done(hs["bidx"])
+                        elif dl is not None:
                             ops.instnorm_act_bwd_head(dl, hs["w"].view(hs["k"], -1), a["y"].act, a["stats"], dy, a["slope"])
                         elif a.get("m12_valid"):      # the two means came out of the backward-data kernel that completed gout
                             a["m12_valid"] = False
@@ -1306,6 +1328,31 @@ class Plan:
     def _fill_image_t(self):
         if self._image_t is not None:
             self._image_t.act.t[..., :self.Cin].copy_(self._x.permute(0, 2, 3, 4, 1))
+
+    def run_encoder(self, x):
+        """the encoder part of the forward list alone (eager launches): the per-stage outputs (`Encoder.forward`'s skips) as NCDHW
+        fp32 tensors.  Stage outputs that live inside a decoder's concat buffer are read through their channel view."""
+        if tuple(x.shape) != self.in_shape:
+            raise ValueError(f"plan built for input {self.in_shape}, got {tuple(x.shape)}")
+        x = x.detach()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        self._apply_act = False
+        self._forward_pre()
+        self._x = x.unsqueeze(2) if self.two_d else x
+        self._fill_image_t()
+        self.refresh_packs(force=False)
+        n = self.n_fwd_enc if self.n_fwd_enc is not None else len(self.fwd)
+        for step in self.fwd[:n]:
+            step()
+        for ent in self.packs:
+            self._await_pack(ent)
+        outs = []
+        for at, c in self.enc_skips:
+            t = at.act.to_ncdhw()[:, :c].float()
+            outs.append(t.squeeze(2) if self.two_d else t)
+        self.generation += 1
+        return outs
 
     def _backward_body(self):
         self._dy_free.clear()       # the previous backward ended with the side stream joined: nothing is still read

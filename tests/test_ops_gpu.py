@@ -529,6 +529,22 @@ def test_instnorm_act_bwd_head_is_head_bwd_then_instnorm_bwd(ops, dtype, k, slop
     torch.cuda.synchronize()
     assert torch.equal(dy1.t, dy2.t)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    # round 3: the head's own dw / db out of the same reduce pass, the activation recomputed from y (`out` here must then BE the
+    # activation of y: rebuild it with the forward kernel) -- no head_bwd launch, dy unchanged bit for bit
+    b0 = torch.zeros((k,), device="cuda")
+    logits = torch.empty((n, k, *dims), device="cuda")
+    act_out = ops.Act.empty(n, *dims, c, dtype)
+    ops.instnorm_act_head_fwd(y, stats, act_out, w, b0, logits, 0, slope)
+    logits2 = torch.empty_like(logits)
+    ops.instnorm_act_head_fwd(y, stats, None, w, b0, logits2, 0, slope)            # nobody needs the activated output: not stored
+    dw_ref, db_ref = torch.empty_like(dw), torch.empty_like(db)
+    ops.head_bwd(dout, act_out, w, None, dw_ref, db_ref)
+    dw3, db3, dy3 = torch.empty_like(dw), torch.empty_like(db), ops.Act.empty(n, *dims, c, dtype)
+    ops.instnorm_act_bwd_head(dout, w, y, stats, dy3, slope, dw=dw3, db=db3)
+    torch.cuda.synchronize()
+    assert torch.equal(logits, logits2)
+    assert torch.equal(dy3.t, dy2.t)
+    assert rel(dw3, dw_ref) < 2e-5 and rel(db3, db_ref) < 2e-5, (rel(dw3, dw_ref), rel(db3, db_ref))
     # fp64 reference of the same arithmetic
     yd = y.t.double()
     mean, rstd = stats[..., 0].double().view(n, 1, 1, 1, c), stats[..., 1].double().view(n, 1, 1, 1, c)
