@@ -551,6 +551,8 @@ def test_channel_dropout_on_the_fused_paths(NetworkFromConfig):
             # the activations after a dropped plane's InstanceNorm are exactly zero
             inacts = [r for tape in [plan.enc_tape] + plan.dec_tapes for r in tape if r.kind == "inact" and r.a["drop"] is not None]
             for i, r in enumerate(inacts):
+                if r.a.get("head_dw_fused"):                 # the layer under a task head does not store its activated output (round 3)
+                    continue
                 a = r.a["out"].act.tensor().float()          # (N, Z, Y, X, C)
                 dropped = masks[i] == 0
                 if dropped.any():
