@@ -5,7 +5,7 @@
 # WRITE_SIZE) as MI355X_MICROARCH.md prescribes (never combined with trace domains).  Summaries land in gpurun_out/<tag>_*;
 # copy what should be judged into profiles/.
 set -o pipefail
-TAG=${1:-r02_a}
+TAG=${1:-r03_a}
 OUT=gpurun_out
 export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 5 --through-trainer > $OUT/${TAG}_bench_cfg2.json 2> $OUT/${TAG}_bench.err || exit 1
