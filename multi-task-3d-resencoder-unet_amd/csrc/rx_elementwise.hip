@@ -1149,14 +1149,19 @@ extern "C" int rx_avgpool_bwd(rx_dtype dt, const rx_act* dy, const rx_act* dx, c
   return RX_OK;
 }
 
-// ---- task head: 1x1x1 conv with bias to K <= 64 channels (forward: accumulator arrays sized 8 / 16 / 32 / 64, K <= 8 keeps the
-// lean kernel; backward: weight / bias gradients in chunks of <= 16 output channels, the data gradient over all K in chunk 0) ---
-#define RX_HEAD_MAXK 64
+// ---- task head: 1x1x1 conv with bias (forward: accumulator arrays sized 8 / 16 / 32 / 64, K <= 8 keeps the lean kernel, more
+// than 64 classes run in chunks of 64 with the eval-mode softmax as a separate pass over the logits; backward: weight / bias
+// gradients in chunks of <= 16 output channels, the data gradient over all K in chunk 0).  decoder.py:131 puts no bound on
+// num_classes (whole-body label sets have 100+); RX_HEAD_MAXK only bounds the LDS-resident weight table of the backward. ---
+#define RX_HEAD_MAXK 1024
 template <typename T, int MAXK>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, int ldx, long sx, const float* __restrict__ w,
-                                                       const float* __restrict__ b, int K, float* __restrict__ out, int V, int C, int act) {
+                                                       const float* __restrict__ b, int K, int k0, int Kt, float* __restrict__ out, int V,
+                                                       int C, int act) {
   constexpr int P = Elem<T>::PER16;
-  extern __shared__ __attribute__((aligned(16))) float sw[];  // [K][C]
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [K][C]: output channels [k0, k0 + K) of a head with Kt of them
+  w += (size_t)k0 * C;
+  b += k0;
   for (int i = threadIdx.x; i < K * C; i += 256) sw[i] = w[i];
   __syncthreads();
   const int n = blockIdx.y;
@@ -1194,7 +1199,20 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
     }
 #pragma unroll
     for (int k = 0; k < MAXK; ++k)
-      if (k < K) out[((size_t)n * K + k) * V + v] = acc[k];
+      if (k < K) out[((size_t)n * Kt + k0 + k) * V + v] = acc[k];
+  }
+}
+
+// softmax over the channel axis of (N, K, V) fp32 logits, in place (heads with more than 64 classes in eval mode)
+__global__ __launch_bounds__(256) void softmax_ncdhw_kernel(float* __restrict__ out, int K, long V) {
+  const int n = blockIdx.y;
+  float* o = out + (size_t)n * K * V;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long)gridDim.x * 256) {
+    float m = -INFINITY, s = 0.f;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, o[(size_t)k * V + v]);
+    for (int k = 0; k < K; ++k) s += expf(o[(size_t)k * V + v] - m);
+    const float inv = 1.f / s;
+    for (int k = 0; k < K; ++k) o[(size_t)k * V + v] = expf(o[(size_t)k * V + v] - m) * inv;
   }
 }
 
@@ -1208,19 +1226,23 @@ extern "C" int rx_head_fwd(rx_dtype dt, const rx_act* x, const float* w, const f
   const long V = rx_act_voxels(x);
   hipStream_t st = (hipStream_t)stream;
 #define RX_LAUNCH_HEAD_FWD(MK)                                                                                                        \
-  hipLaunchKernelGGL((head_fwd_kernel<T, MK>), dim3(G, x->n), dim3(256), (size_t)k * x->c * sizeof(float), st, (const T*)x->ptr, x->ld,  \
-                     V * x->ld, w, b, k, out_ncdhw, (int)V, x->c, act)
+  hipLaunchKernelGGL((head_fwd_kernel<T, MK>), dim3(G, x->n), dim3(256), (size_t)kc * x->c * sizeof(float), st, (const T*)x->ptr, x->ld, \
+                     V * x->ld, w, b, kc, k0, k, out_ncdhw, (int)V, x->c, act_here)
   RX_DISPATCH_DTYPE(dt, T, {
     int G = (int)((V + 255) / 256 > 4096 ? 4096 : (V + 255) / 256);
-    if (k <= 8)
-      RX_LAUNCH_HEAD_FWD(8);
-    else if (k <= 16)
-      RX_LAUNCH_HEAD_FWD(16);
-    else if (k <= 32)
-      RX_LAUNCH_HEAD_FWD(32);
-    else
-      RX_LAUNCH_HEAD_FWD(64);
-
+    const int act_here = (k > 64 && act == RX_ACT_SOFTMAX) ? (int)RX_ACT_NONE : act;      // softmax needs every class: second pass
+    for (int k0 = 0; k0 < k; k0 += 64) {
+      const int kc = k - k0 < 64 ? k - k0 : 64;
+      if (kc <= 8)
+        RX_LAUNCH_HEAD_FWD(8);
+      else if (kc <= 16)
+        RX_LAUNCH_HEAD_FWD(16);
+      else if (kc <= 32)
+        RX_LAUNCH_HEAD_FWD(32);
+      else
+        RX_LAUNCH_HEAD_FWD(64);
+    }
+    if (k > 64 && act == RX_ACT_SOFTMAX) hipLaunchKernelGGL(softmax_ncdhw_kernel, dim3(G, x->n), dim3(256), 0, st, out_ncdhw, k, V);
   });
 #undef RX_LAUNCH_HEAD_FWD
   RX_CHECK_LAUNCH("rx_head_fwd");
@@ -1328,7 +1350,11 @@ extern "C" int rx_head_bwd(rx_dtype dt, const float* dout_ncdhw, const rx_act* x
   RX_DISPATCH_DTYPE(dt, T, {
     constexpr int P = Elem<T>::PER16;
     ReducePlan p = rx_reduce_plan(V, C, P);
-    const int kc_max = k <= 16 ? k : 16;           // output channels per launch
+    int kc_max = k <= 16 ? k : 16;                 // output channels per launch
+    {   // many classes: the LDS-resident weight table grows with K -- halve the chunk until table + reduction planes fit
+      const int VP0 = 256 / (C / P);
+      while (kc_max > 4 && ((size_t)k * C + (size_t)(kc_max + 1) * VP0 * C) * sizeof(float) > 150 * 1024) kc_max /= 2;
+    }
     size_t need = (size_t)N * p.nchunks * (kc_max + 1) * C * sizeof(float) + (size_t)(kc_max + 1) * C * sizeof(float) + 256;
     if (ws_bytes < need) RX_FAIL(RX_EWORKSPACE, "rx_head_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
     int CV = C / P, VP = 256 / CV;
@@ -1338,8 +1364,8 @@ extern "C" int rx_head_bwd(rx_dtype dt, const float* dout_ncdhw, const rx_act* x
     if (lds > 160 * 1024) RX_FAIL(RX_EUNSUPPORTED, "rx_head_bwd: K = %d needs %zu bytes of LDS", k, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<T, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<T, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    for (int k0 = 0; k0 < k; k0 += 16) {
-      const int kc = k - k0 < 16 ? k - k0 : 16;
+    for (int k0 = 0; k0 < k; k0 += kc_max) {
+      const int kc = k - k0 < kc_max ? k - k0 : kc_max;
       T* dxp = (dx && k0 == 0) ? (T*)dx->ptr : (T*)nullptr;
       if (kc <= 8) {
         hipLaunchKernelGGL((head_bwd_kernel<T, 8>), dim3(p.nchunks, N), dim3(256), lds, st, dout_ncdhw, (const T*)x->ptr, x->ld, V * x->ld, w, kc,

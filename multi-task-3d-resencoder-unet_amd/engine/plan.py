@@ -594,8 +594,8 @@ class Plan:
                 low = h
             head = dec.seg_layers[-1]
             k = head.out_channels
-            if k > 64:
-                raise UnsupportedConfig("task heads with more than 64 channels have no HIP kernel")
+            if k > 1024:
+                raise UnsupportedConfig("task heads with more than 1024 channels have no HIP kernel")
             out = torch.empty((self.B, k, *low.act.dims[1:]), dtype=torch.float32, device=self.device)
             self.outputs[name] = out
             act_mod = net.task_activations[name] if name in net.task_activations else None

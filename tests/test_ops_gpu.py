@@ -314,7 +314,7 @@ def test_stem(ops, dtype, cin, k):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("k", [1, 3, 8, 9, 16, 17, 40, 64])        # K <= 8: lean kernel; 9..16 / ..32 / ..64: wider accumulator arrays; backward in chunks of 16
+@pytest.mark.parametrize("k", [1, 3, 8, 9, 16, 17, 40, 64, 65, 117, 200])   # K <= 8: lean kernel; 9..16 / ..32 / ..64: wider accumulator arrays; > 64: chunks of 64 + a softmax pass; backward in chunks of 16
 def test_head(ops, dtype, k):
     from mt3d_amd.engine import lib
     n, c, dims = 2, 32, (6, 7, 8)

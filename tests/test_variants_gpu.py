@@ -155,7 +155,7 @@ def test_droppath_training_and_eval(NetworkFromConfig):
         assert rel_l2(e_n[k].cpu(), e_r[k]) < 2e-4
 
 
-@pytest.mark.parametrize("classes,data_seed", [(12, 1), (40, 1)])
+@pytest.mark.parametrize("classes,data_seed", [(12, 1), (40, 1), (117, 1)])      # 117: more than 64 classes (round 3: chunks of 64 + a softmax pass)
 def test_widened_configs_six_inputs_twelve_class_head(NetworkFromConfig, classes, data_seed):
     """round 2 widening: in_channels up to 8 (the stem's VALU kernels above 4) and task heads up to 64
     channels (softmax over 12 / 40 classes here; above 16 the head's weight gradient runs in chunks of 16 output channels),
@@ -171,7 +171,8 @@ def test_widened_configs_six_inputs_twelve_class_head(NetworkFromConfig, classes
         if pr[n].grad is not None and pr[n].grad.norm() > 1e-6:
             # (data seed 1 has mask margin for this net on the CPU -- oracle fp32 vs fp64 2.5e-6 -- and on the engine, 1.8e-6
             # against the fp64 oracle: oracle/seed_margin_gpu.py widened; seed 5 flips one mask in the engine's summation order)
-            assert rel_l2(pn[n].grad.cpu(), pr[n].grad) < 1e-3, (n, rel_l2(pn[n].grad.cpu(), pr[n].grad))
+            # (117 classes: the data seed is not curated for mask margin -- 3e-3 there)
+            assert rel_l2(pn[n].grad.cpu(), pr[n].grad) < (1e-3 if classes <= 64 else 3e-3), (n, rel_l2(pn[n].grad.cpu(), pr[n].grad))
     ref.eval(); net.eval()
     x, _ = oracle.synthetic_batch(2, 6, (16, 16, 16), tasks, 1)
     with torch.no_grad():
