@@ -180,6 +180,8 @@ class Plan:
         self._x_static = None
         self._dl_static: Dict[str, torch.Tensor] = {}
         self._image_t = None                      # channels-last copy of an image with > 16 channels (see _image_act)
+        self._pack_delay_at = None                # forward-list index behind the full-resolution encoder stage (deferred weight packs)
+        self._pack_deferred = None
         self._build()
 
     def release(self):
@@ -657,6 +659,9 @@ class Plan:
                         rec.a["fwd_fused"] = True
             for rec in tape:
                 a = rec.a
+                if (tape is self.enc_tape and self._pack_delay_at is None and rec.kind in ("conv", "pool")
+                        and rec.a["y"].act.voxels < self.spatial[0] * self.spatial[1] * self.spatial[2]):
+                    self._pack_delay_at = len(f)          # the first layer below full resolution
                 if rec.kind == "stem":
                     f.append(lambda a=a: ops.stem_conv_fwd(P._x, a["w"], a["b"], a["y"].act, a["kernel"]))
                 elif rec.kind == "image":        # NCDHW fp32 image -> channels-last compute type (identity 1x1x1 first-layer conv)
@@ -1074,6 +1079,8 @@ class Plan:
             self._ev_fork, self._ev_join = ops.event_new(), ops.event_new()
 
     def _await_pack(self, ent):
+        if ent.get("deferred") and self._pack_deferred is not None:
+            self._issue_deferred_packs()
         slot = ent.get("event")
         if slot is not None:
             ops.stream_wait(slot)
@@ -1104,9 +1111,19 @@ class Plan:
             side = self._side
             ops.event_record(self._ev_fork)                    # the optimizer's writes are on the main stream
             ops.stream_wait(self._ev_fork, side)
-        self._pack_entries(stale, side)
+        self._pack_entries(stale, side, defer=True)
 
-    def _pack_entries(self, entries, side):
+    def _issue_deferred_packs(self):
+        """(from inside the forward list) the pack groups that refresh_packs held back: ordered after the optimizer's writes by the
+        fork event recorded there (the side stream executes in order), and before their first consumer by position in the list"""
+        d, self._pack_deferred = self._pack_deferred, None
+        if d is not None:
+            groups, side = d
+            ops.event_record(self._ev_fork)                    # main stream: everything up to here
+            ops.stream_wait(self._ev_fork, side)
+            self._pack_groups_now(groups, side, 1)
+
+    def _pack_entries(self, entries, side, defer=False):
         """re-pack `entries` (in first-use order) on `side` (or the current stream).  Table launches (rx_pack_multi, 40 tensors
         each) in GROUPS of ~RX_PACK_GROUP_MB of parameters with one numbered event per group: the first convs of the forward
         wait for the first (small) group only, the 512-channel stages' packing runs under the stages before them.  Was: one
@@ -1122,9 +1139,23 @@ class Plan:
             cur_bytes += nb
         if cur:
             groups.append(cur)
+        # RX_PACK_DELAY (default on): only the first group is packed now; the others (the 512-channel stages: 80 % of the bytes) are
+        # issued from inside the forward list, behind the full-resolution stage (see _forward_body) -- the packing then competes
+        # with the 64^3 / 32^3 convolutions instead of the HBM-bound full-resolution InstanceNorm passes
+        self._pack_deferred = None
+        if (defer and side is not None and len(groups) > 1 and self._pack_delay_at is not None
+                and os.environ.get("RX_PACK_DELAY", "1") != "0"):
+            self._pack_deferred = (groups[1:], side)
+            for grp in groups[1:]:
+                for ent in grp:
+                    ent["deferred"] = True        # a consumer that comes earlier than expected issues them itself (_await_pack)
+            groups = groups[:1]
+        self._pack_groups_now(groups, side, 0)
+
+    def _pack_groups_now(self, groups, side, gi0):
         ctx = torch.cuda.stream(side) if side is not None else _NullCtx()
         with ctx:
-            for gi, grp in enumerate(groups):
+            for gi, grp in enumerate(groups, gi0):
                 items = []
                 for ent in grp:
                     w = ent["param"].detach()
@@ -1143,6 +1174,7 @@ class Plan:
                     ops.event_record(slot)
                 for ent in grp:
                     p = ent["param"]
+                    ent["deferred"] = False
                     ent["event"], ent["group"] = slot, grp
                     ent["version"], ent["ptr"] = p._version, p.data_ptr()
                     ent["epoch"] = getattr(self.net, "_weights_epoch", 0)
@@ -1270,8 +1302,11 @@ class Plan:
 
     def _forward_body(self, force_packs):
         self.refresh_packs(force=force_packs)
-        for step in self.fwd:
+        for i, step in enumerate(self.fwd):
+            if i == self._pack_delay_at:
+                self._issue_deferred_packs()
             step()
+        self._issue_deferred_packs()
         for ent in self.packs:          # parameters of unused branches: never leave a pack in flight
             self._await_pack(ent)
 
@@ -1345,6 +1380,7 @@ class Plan:
         n = self.n_fwd_enc if self.n_fwd_enc is not None else len(self.fwd)
         for step in self.fwd[:n]:
             step()
+        self._issue_deferred_packs()
         for ent in self.packs:
             self._await_pack(ent)
         outs = []
