@@ -116,9 +116,41 @@ def test_low_precision_modes_against_oracle(NetworkFromConfig, case, dtype, ltol
             assert cosine(params[n].grad, g[f"grad.{n}"]) > cos_min, n
 
 
+def test_fp32_live_oracle_32cube_every_cpu_clean_seed(NetworkFromConfig):
+    """the data seed of the two-step test below used to be picked by looking at the ENGINE's error (oracle/seed_margin_gpu.py)
+    -- selection on the system under test.  Here the seeds are chosen by the CPU-only criterion alone (oracle fp32 vs its own fp64
+    evaluation < 3e-5 at two thread counts, oracle/scan_seeds.py procedure; of data seeds 1..30 and 107 exactly these six qualify, the
+    other 25 flip a LeakyReLU mask on the CPU itself) and ALL of them run: logits 2e-4 and identical decisions on every seed; gradients
+    within 1e-3 of the oracle on at least four of the six, and never beyond a single mask flip (1e-2).  Measured: 4.3e-6 .. 4.5e-6 on
+    seeds 4, 16, 23, 107; 3.6e-3 / 1.5e-3 on seeds 1 / 2, where the engine's fp32 summation order flips one mask the CPU's does not."""
+    tasks = {"sheet": {"channels": 1, "activation": "sigmoid", "loss_fn": "BCEDiceLoss",
+                       "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
+    mgr = oracle.make_mgr((32, 32, 32), tasks, 1, 1, True, {})
+    torch.manual_seed(5)
+    ref = oracle.NetworkFromConfig(mgr)
+    torch.manual_seed(5)
+    net = NetworkFromConfig(mgr).cuda()
+    worst = {}
+    for ds in (1, 2, 4, 16, 23, 107):
+        x, targets = oracle.synthetic_batch(1, 1, (32, 32, 32), tasks, ds)
+        ref.train(); net.train()
+        o_r, o_n = ref(x), net(x.cuda())
+        assert rel_l2(o_n["sheet"].cpu(), o_r["sheet"].detach()) < 2e-4
+        assert torch.equal(o_n["sheet"].cpu() > 0, o_r["sheet"] > 0)
+        ref.zero_grad(); net.zero_grad()
+        oracle.train_loss(o_r, targets, tasks).backward()
+        oracle.train_loss(o_n, {k: v.cuda() for k, v in targets.items()}, tasks).backward()
+        pr, pn = dict(ref.named_parameters()), dict(net.named_parameters())
+        worst[ds] = max(rel_l2(pn[n].grad.cpu(), pr[n].grad) for n in pr if pr[n].grad is not None and pr[n].grad.norm() > 1e-6)
+    print("32^3 live oracle, worst gradient rel-L2 per CPU-clean data seed:", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert sum(v < 1e-3 for v in worst.values()) >= 4, worst
+    assert max(worst.values()) < 1e-2, worst
+
+
 def test_fp32_live_oracle_32cube_two_steps(NetworkFromConfig):
     """a deeper net (32^3 -> 4 stages) against the oracle run live, plus: a second step after an
-    in-place parameter update must see the new weights (packed copies are refreshed by version)."""
+    in-place parameter update must see the new weights (packed copies are refreshed by version).  (Data seed 107 is one of the four of
+    six CPU-clean seeds on which the engine flips no mask either -- the test above runs all six.)"""
     tasks = {"sheet": {"channels": 1, "activation": "sigmoid", "loss_fn": "BCEDiceLoss",
                        "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
     mgr = oracle.make_mgr((32, 32, 32), tasks, 1, 1, True, {})
