@@ -76,10 +76,66 @@ def NetworkFromConfig():
     return N
 
 
+def draw_geometry(rng):
+    """round 3: the conv geometries and widths the engine used to refuse -- kernel sizes 1 / 3 / 5 / 7, strides 1..4 per axis and
+    stage, 1..40 input channels, wide stems, heads beyond 64 classes, with the block / decoder variety of `draw`"""
+    two_d = rng.random() < 0.2
+    nd = 2 if two_d else 3
+    n_st = rng.choice([2, 2, 3])
+    base = rng.choice([16, 32, 32])
+    feats = [min(base * 2 ** i, 64) for i in range(n_st)]
+    enc = rng.choice(["BasicBlockD", "BasicBlockD", "BottleneckBlockD", "ResidualBlock"])
+    dec = rng.choice(["ConvBlock", "ConvBlock", "ResidualBlock"])
+    kernels, strides = [], []
+    for s in range(n_st):
+        k = [rng.choice([1, 3, 3, 5, 5, 7]) for _ in range(nd)]      # (odd: an even kernel shrinks the map under pad (k-1)//2 and the
+        if all(v == 1 for v in k):                                   #  reference's own residual adds / concats then fail; op-level tests cover them)
+            k[-1] = 5
+        if s == 0:
+            st = [rng.choice([1, 1, 1, 2, 3]) for _ in range(nd)] if rng.random() < 0.3 else [1] * nd
+        else:
+            st = [rng.choice([1, 2, 2, 3, 4]) for _ in range(nd)]
+            if all(v == 1 for v in st):
+                st[-1] = rng.choice([2, 3, 4])
+        kernels.append(k), strides.append(st)
+    total = [1] * nd
+    for st in strides:
+        total = [a * b for a, b in zip(total, st)]
+    patch = tuple(t * rng.choice([2, 3] if t >= 6 else [3, 4, 6]) for t in total)
+    mc = {"basic_encoder_block": enc, "basic_decoder_block": dec,
+          "bottleneck_block": "BottleneckBlockD" if enc == "BottleneckBlockD" else "BasicBlockD",
+          "features_per_stage": feats, "num_stages": n_st, "n_blocks_per_stage": [rng.choice([1, 2]) for _ in range(n_st)],
+          "kernel_sizes": kernels, "n_conv_per_stage_decoder": [1] * (n_st - 1), "strides": strides,
+          "conv_bias": rng.random() < 0.5, "nonlin": "nn.LeakyReLU"}
+    if rng.random() < 0.25:
+        mc["do_stem"] = False
+    elif rng.random() < 0.3:
+        mc["stem_channels"] = rng.choice([72, 96])
+    classes = rng.choice([1, 2, 3, 70, 100])
+    act = "softmax" if classes > 1 and rng.random() < 0.6 else ("sigmoid" if rng.random() < 0.5 else "none")
+    tasks = {"t": {"channels": classes, "activation": act, "weight": 1, "loss_fn": "BCEDiceLoss", "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
+    return dict(patch=patch, cin=rng.choice([1, 2, 5, 17, 24, 33, 40]), batch=rng.choice([1, 2]), mc=mc, tasks=tasks)
+
+
+def geometry_configs(n=24, seed=30303):
+    seed = int(__import__("os").environ.get("RX_FUZZ_SEED", seed))
+    rng = random.Random(seed)
+    return [draw_geometry(rng) for _ in range(n)]
+
+
+@pytest.mark.parametrize("i", range(24))
+def test_random_geometry_matches_the_oracle(NetworkFromConfig, i):
+    """24 draws of `draw_geometry` against the CPU oracle in fp32 mode, same bars as test_random_config_matches_the_oracle"""
+    _check_against_oracle(NetworkFromConfig, geometry_configs()[i], i)
+
+
 @pytest.mark.parametrize("i", range(36))
 def test_random_config_matches_the_oracle(NetworkFromConfig, i):
+    _check_against_oracle(NetworkFromConfig, configs()[i], i)
+
+
+def _check_against_oracle(NetworkFromConfig, c, i):
     from mt3d_amd.engine.plan import UnsupportedConfig
-    c = configs()[i]
     mgr = oracle.make_mgr(c["patch"], c["tasks"], c["cin"], c["batch"], False, c["mc"])
     torch.manual_seed(100 + i)
     try:
