@@ -127,18 +127,18 @@ def test_fp32_live_oracle_32cube_every_cpu_clean_seed(NetworkFromConfig):
                        "loss_kwargs": {"alpha": 0.5, "beta": 0.5}}}
     mgr = oracle.make_mgr((32, 32, 32), tasks, 1, 1, True, {})
     torch.manual_seed(5)
-    ref = oracle.NetworkFromConfig(mgr)
+    ref = oracle.NetworkFromConfig(mgr).double()      # the fp64 evaluation: no mask ambiguity on the reference side
     torch.manual_seed(5)
     net = NetworkFromConfig(mgr).cuda()
     worst = {}
     for ds in (1, 2, 4, 16, 23, 107):
         x, targets = oracle.synthetic_batch(1, 1, (32, 32, 32), tasks, ds)
         ref.train(); net.train()
-        o_r, o_n = ref(x), net(x.cuda())
+        o_r, o_n = ref(x.double()), net(x.cuda())
         assert rel_l2(o_n["sheet"].cpu(), o_r["sheet"].detach()) < 2e-4
         assert torch.equal(o_n["sheet"].cpu() > 0, o_r["sheet"] > 0)
         ref.zero_grad(); net.zero_grad()
-        oracle.train_loss(o_r, targets, tasks).backward()
+        oracle.train_loss(o_r, {k: v.double() for k, v in targets.items()}, tasks).backward()
         oracle.train_loss(o_n, {k: v.cuda() for k, v in targets.items()}, tasks).backward()
         pr, pn = dict(ref.named_parameters()), dict(net.named_parameters())
         worst[ds] = max(rel_l2(pn[n].grad.cpu(), pr[n].grad) for n in pr if pr[n].grad is not None and pr[n].grad.norm() > 1e-6)
