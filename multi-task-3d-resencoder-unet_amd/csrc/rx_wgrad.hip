@@ -197,40 +197,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ sl
   }
 }
 
-// many-splits variant (small R*C, e.g. 32x32 panels with 256 slabs): one block per (64 pairs, tap).  A 32 -> 32 layer has only
-// 1024 (r, c) pairs: with one thread per pair the launch was 108 workgroups summing 256 slabs each (28 MB at 1.2 TB/s, 23 us, 37
-// launches per cfg2 step).  Now the four WAVES of a block share 64 pairs -- wave w sums the slabs k = w (mod 4) in ascending
-// order (256-byte coalesced reads, 8 independent loads in flight) and the four partial sums are combined through LDS in a FIXED
-// order ((w0 + w1) + (w2 + w3)): deterministic, 4x the parallelism.  Output writes are stride-T but the tensors of this regime
-// are tiny.
+// many-splits variant (small R*C, e.g. 32x32 panels with 512 slabs): one block per (256 pairs, tap); the loop over
+// the splits is 8-way unrolled so every wave keeps 8 independent 1-KB loads in flight.  Output writes are
+// stride-T but the tensors of this regime are tiny.
 __global__ __launch_bounds__(256) void wgrad_reduce_manysplits(const float* __restrict__ slab, int S, int T_, int R, int C,
                                                                float* __restrict__ dw) {
-  __shared__ float red[4][64];
   const long RC = (long)R * C;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + lane;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const int t = blockIdx.y;
-  const bool ok = i < RC;
-  const float* p = slab + (long)t * RC + (ok ? i : 0);
+  if (i >= RC) return;
+  const float* p = slab + (long)t * RC + i;
   const long stride = (long)T_ * RC;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
-  if (ok) {
-    int k = w;
-    for (; k + 28 < S; k += 32) {
-      a0 += p[(long)(k + 0) * stride];
-      a1 += p[(long)(k + 4) * stride];
-      a2 += p[(long)(k + 8) * stride];
-      a3 += p[(long)(k + 12) * stride];
-      a4 += p[(long)(k + 16) * stride];
-      a5 += p[(long)(k + 20) * stride];
-      a6 += p[(long)(k + 24) * stride];
-      a7 += p[(long)(k + 28) * stride];
-    }
-    for (; k < S; k += 4) a0 += p[(long)k * stride];
+  int k = 0;
+  for (; k + 8 <= S; k += 8) {
+    a0 += p[(k + 0) * stride];
+    a1 += p[(k + 1) * stride];
+    a2 += p[(k + 2) * stride];
+    a3 += p[(k + 3) * stride];
+    a4 += p[(k + 4) * stride];
+    a5 += p[(k + 5) * stride];
+    a6 += p[(k + 6) * stride];
+    a7 += p[(k + 7) * stride];
   }
-  red[w][lane] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
-  __syncthreads();
-  if (w == 0 && ok) dw[i * T_ + t] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  for (; k < S; ++k) a0 += p[k * stride];
+  dw[i * T_ + t] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -315,7 +306,7 @@ static int conv_out_dim(int in, int k, int s) { return (in + 2 * ((k - 1) / 2) -
 void rx_wgrad_reduce_launch(const float* slab, int S, int T_, int R, int C, float* dw, hipStream_t st) {
   long RC = (long)R * C;
   if (S >= 8 || T_ > 27)       // (wgrad_reduce transposes a [256][T <= 27] tile through LDS)
-    hipLaunchKernelGGL(wgrad_reduce_manysplits, dim3((unsigned)((RC + 63) / 64), T_), dim3(256), 0, st, slab, S, T_, R, C, dw);
+    hipLaunchKernelGGL(wgrad_reduce_manysplits, dim3((unsigned)((RC + 255) / 256), T_), dim3(256), 0, st, slab, S, T_, R, C, dw);
   else
     hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((RC + 255) / 256)), dim3(256), 0, st, slab, S, T_, R, C, dw);
 }
