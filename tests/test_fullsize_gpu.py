@@ -288,6 +288,7 @@ def test_cfg2_full_size_fp32_against_the_cpu_oracle():
     import mt3d_amd  # noqa: F401
     from mt3d_amd.builders.build_network_from_config import NetworkFromConfig
     patch, B = (128, 128, 128), 1
+    threads_before = torch.get_num_threads()
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     mgr = oracle.make_mgr(patch, TASKS, 1, B, True, {})
     x, t = oracle.synthetic_batch(B, 1, patch, TASKS, int(os.environ.get("RX_TEST_CFG2_SEED", "2")))
@@ -331,3 +332,4 @@ def test_cfg2_full_size_fp32_against_the_cpu_oracle():
         assert d_eng[n] <= 3e-2, (n, d_eng[n], d_cpu[n])
     net._apply(lambda z: z)          # drop the plans (a 128^3 fp32 plan holds ~15 GB)
     torch.cuda.empty_cache()
+    torch.set_num_threads(threads_before)      # (the CPU oracle's fp32 summation order -- and with it which masks flip -- follows the thread count)

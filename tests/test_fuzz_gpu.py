@@ -125,8 +125,11 @@ def geometry_configs(n=24, seed=30303):
 
 @pytest.mark.parametrize("i", range(24))
 def test_random_geometry_matches_the_oracle(NetworkFromConfig, i):
-    """24 draws of `draw_geometry` against the CPU oracle in fp32 mode, same bars as test_random_config_matches_the_oracle"""
-    _check_against_oracle(NetworkFromConfig, geometry_configs()[i], i)
+    """24 draws of `draw_geometry` against the CPU oracle evaluated in fp64, same bars as test_random_config_matches_the_oracle.
+    (fp64: torch's fp32 CPU convolution backward is not a usable reference for some of these geometries -- draw 22, a [7, 1, 3]
+    kernel at stride [2, 2, 4], comes out uncorrelated with the fp64 evaluation at 1-32 threads (cosine 0.001-0.01) and right at
+    128; the engine agrees with fp64 to 1 - 4e-13.  scripts/probes/geom22_probe.py)"""
+    _check_against_oracle(NetworkFromConfig, geometry_configs()[i], i, oracle_dtype=torch.float64)
 
 
 @pytest.mark.parametrize("i", range(36))
@@ -134,12 +137,12 @@ def test_random_config_matches_the_oracle(NetworkFromConfig, i):
     _check_against_oracle(NetworkFromConfig, configs()[i], i)
 
 
-def _check_against_oracle(NetworkFromConfig, c, i):
+def _check_against_oracle(NetworkFromConfig, c, i, oracle_dtype=torch.float32):
     from mt3d_amd.engine.plan import UnsupportedConfig
     mgr = oracle.make_mgr(c["patch"], c["tasks"], c["cin"], c["batch"], False, c["mc"])
     torch.manual_seed(100 + i)
     try:
-        ref = oracle.NetworkFromConfig(mgr)
+        ref = oracle.NetworkFromConfig(mgr).to(oracle_dtype)
     except (ValueError, AssertionError, RuntimeError, IndexError) as e:       # a topology the reference itself cannot build
         pytest.skip(f"oracle refuses: {type(e).__name__}: {e}")
     torch.manual_seed(100 + i)
@@ -148,7 +151,7 @@ def _check_against_oracle(NetworkFromConfig, c, i):
     assert list(ref.state_dict().keys()) == list(net.state_dict().keys())
     x, t = oracle.synthetic_batch(c["batch"], c["cin"], c["patch"], c["tasks"], 7 + i)
     try:
-        o_r = ref(x)
+        o_r = ref(x.to(oracle_dtype))
     except (RuntimeError, ValueError) as e:                                   # e.g. concat size mismatch of an odd topology
         pytest.skip(f"oracle forward fails: {e}")
     try:
@@ -158,7 +161,7 @@ def _check_against_oracle(NetworkFromConfig, c, i):
     for k in o_r:
         assert rel_l2(o_n[k].cpu(), o_r[k].detach()) < 2e-4, (c, k)
     t = targets_for(c, o_r, 7 + i)
-    l_r = oracle.train_loss(o_r, t, c["tasks"])
+    l_r = oracle.train_loss(o_r, {k: v.to(oracle_dtype) for k, v in t.items()}, c["tasks"])
     l_n = oracle.train_loss(o_n, {k: v.cuda() for k, v in t.items()}, c["tasks"])
     assert abs(l_r.item() - l_n.item()) < 1e-4 * max(1.0, abs(l_r.item()))
     l_r.backward()
@@ -179,7 +182,7 @@ def _check_against_oracle(NetworkFromConfig, c, i):
         assert cos > 0.99 and abs(a.norm().item() / b.norm().item() - 1) < 3e-2, (c, n, cos, a.norm().item() / b.norm().item())
     ref.eval(); net.eval()
     with torch.no_grad():
-        e_r, e_n = ref(x), net(x.cuda())
+        e_r, e_n = ref(x.to(oracle_dtype)), net(x.cuda())
     for k in e_r:
         assert rel_l2(e_n[k].cpu(), e_r[k]) < 2e-4, (c, k)
 
