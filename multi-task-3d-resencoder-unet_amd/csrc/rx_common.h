@@ -1,6 +1,7 @@
 // rx_common.h -- shared device/host helpers for librxunet (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -164,6 +165,19 @@ static inline bool rx_act_ok_planar(const rx_act* a) {
     return a->ptr && a->n > 0 && a->z > 0 && a->y > 0 && a->x > 0 && a->ld == 32 && a->c > 32 && a->c % 32 == 0 && a->cs > 0 && a->cs % 8 == 0;
   return rx_act_ok(a);
 }
+
+// Epilogues: `bias != nullptr` and `g.accumulate` are launch-uniform, but tested per VALUE inside the unrolled stores they cost a
+// scalar branch + s_waitcnt each (conv_halo64ws: 900 instructions, 122 branches between the last MFMA and the last store of a tile,
+// ~1.9 us of a 7.6 us tile with the matrix pipe idle -- found with the RX_DBG=8 / 16 ablations, round 3).  RX_EPI_DISPATCH runs
+// `body(HB, RA)` with the two flags as compile-time constants behind ONE uniform branch; the bias of a lane's 4 consecutive
+// channels is one 16-byte load.
+#define RX_EPI_DISPATCH(has_bias, rt_acc, body)                                                                     \
+  do {                                                                                                              \
+    if (!(has_bias) && !(rt_acc)) body(std::integral_constant<bool, false>{}, std::integral_constant<bool, false>{}); \
+    else if ((has_bias) && !(rt_acc)) body(std::integral_constant<bool, true>{}, std::integral_constant<bool, false>{}); \
+    else if (!(has_bias)) body(std::integral_constant<bool, false>{}, std::integral_constant<bool, true>{});          \
+    else body(std::integral_constant<bool, true>{}, std::integral_constant<bool, true>{});                            \
+  } while (0)
 
 // ---- tap tables and MFMA wrappers shared by the implicit-GEMM and weight-gradient kernels ------
 // kernel sizes 1..7 and strides 1..4 per axis (the reference passes any `kernel_sizes` / `strides` of a manual model_config

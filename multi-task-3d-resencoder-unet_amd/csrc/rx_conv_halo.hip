@@ -203,24 +203,33 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const T* __restrict__
       continue;
     }
     T* op = out + (long)n * g.out_ss + ((long)(z * g.Y + y) * g.X + x) * g.ldo + n0;
+    auto epi = [&](auto HB, auto RA) {
 #pragma unroll
-    for (int a = 0; a < NB; ++a)
+      for (int a = 0; a < NB; ++a)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int co = a * 32 + 8 * g4 + 4 * fh;
-        T vals[4];
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int co = a * 32 + 8 * g4 + 4 * fh;
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+          if (decltype(HB)::value) bv = *reinterpret_cast<const f32x4*>(bias + n0 + co);
+          T old4[4];
+          if (decltype(RA)::value) {
+            if (sizeof(T) == 2) *reinterpret_cast<u32x2*>(old4) = *reinterpret_cast<const u32x2*>(op + co);
+            else *reinterpret_cast<u32x4*>(old4) = *reinterpret_cast<const u32x4*>(op + co);
+          }
+          T vals[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float f = acc[a][b][4 * g4 + i];
-          if (bias) f += bias[n0 + co + i];
-          if (g.accumulate) f += Elem<T>::to_f(op[co + i]);
-          vals[i] = Elem<T>::from_f(f);
+          for (int i = 0; i < 4; ++i) {
+            float f = acc[a][b][4 * g4 + i] + bv[i];
+            if (decltype(RA)::value) f += Elem<T>::to_f(old4[i]);
+            vals[i] = Elem<T>::from_f(f);
+          }
+          if (sizeof(T) == 2)
+            *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
+          else
+            *reinterpret_cast<u32x4*>(op + co) = *reinterpret_cast<u32x4*>(vals);
         }
-        if (sizeof(T) == 2)
-          *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
-        else
-          *reinterpret_cast<u32x4*>(op + co) = *reinterpret_cast<u32x4*>(vals);
-      }
+    };
+    RX_EPI_DISPATCH(bias != nullptr, g.accumulate != 0, epi);
   }
 }
 
@@ -402,27 +411,36 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(const T* __restrict
     const int z = z0 + (v >> 6), y = y0 + ((v >> 4) & 3), x = x0 + (v & 15);
     if (z >= g.Z || y >= g.Y || x >= g.X || RX_ABLATE(g, 8)) continue;
     T* op = out + (long)n * g.out_ss + ((long)(z * g.Y + y) * g.X + x) * g.ldo + n0;
+    auto epi = [&](auto HB, auto RA) {
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int co = 8 * g4 + 4 * fh;
-      T vals[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float f = acc[b][4 * g4 + i];
-        if (bias) f += bias[n0 + co + i];
-        if (g.accumulate) f += Elem<T>::to_f(op[co + i]);
-        vals[i] = Elem<T>::from_f(f);
-        if (STATS) {
-          const float r = Elem<T>::to_f(vals[i]);
-          st1[0][4 * g4 + i] += r;
-          st2[0][4 * g4 + i] += r * r;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int co = 8 * g4 + 4 * fh;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (decltype(HB)::value) bv = *reinterpret_cast<const f32x4*>(bias + n0 + co);
+        T old4[4];
+        if (decltype(RA)::value) {
+          if (sizeof(T) == 2) *reinterpret_cast<u32x2*>(old4) = *reinterpret_cast<const u32x2*>(op + co);
+          else *reinterpret_cast<u32x4*>(old4) = *reinterpret_cast<const u32x4*>(op + co);
         }
+        T vals[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float f = acc[b][4 * g4 + i] + bv[i];
+          if (decltype(RA)::value) f += Elem<T>::to_f(old4[i]);
+          vals[i] = Elem<T>::from_f(f);
+          if (STATS) {
+            const float r = Elem<T>::to_f(vals[i]);
+            st1[0][4 * g4 + i] += r;
+            st2[0][4 * g4 + i] += r * r;
+          }
+        }
+        if (sizeof(T) == 2)
+          *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
+        else
+          *reinterpret_cast<u32x4*>(op + co) = *reinterpret_cast<u32x4*>(vals);
       }
-      if (sizeof(T) == 2)
-        *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
-      else
-        *reinterpret_cast<u32x4*>(op + co) = *reinterpret_cast<u32x4*>(vals);
-    }
+    };
+    RX_EPI_DISPATCH(bias != nullptr, g.accumulate != 0, epi);
   }
   // STATS (deep layers only: one tile per workgroup, but hundreds of MFMAs per wave behind each wavefront reduction): the
   // InstanceNorm sums of this wave's 64 voxels, partial row (tile of the sample, wave)
@@ -586,6 +604,9 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
     float s1[1][16], s2[1][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) s1[0][r] = 0.f, s2[0][r] = 0.f;
+    float bvp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bvp[r] = bias ? bias[8 * (r >> 2) + 4 * fh + (r & 3)] : 0.f;
     float bmean[16];
     if (BS) {
 #pragma unroll
@@ -671,8 +692,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
           T vals[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            float f = acc[b][4 * g4 + i];
-            if (bias) f += bias[co + i];
+            float f = acc[b][4 * g4 + i] + bvp[4 * g4 + i];      // (bias of this lane's 16 channels, loaded once per workgroup)
             if (ACC) f += Elem<T>::to_f(reinterpret_cast<const T*>(&oldv[b][g4])[i]);
             vals[i] = Elem<T>::from_f(f);
             if (STATS) {
@@ -782,6 +802,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
     }
     u32x4 xr[XPIECES], wr[WPIECES];
     auto dma_weights = [&](int ph) {
+      if (RX_ABLATE(g, 2)) return;
       const int r = ph % ppt, cc = r / 3, dzg = r - cc * 3;
       const T* wp = w + dzg * wplane + cc * KB;
       __attribute__((address_space(3))) unsigned char* dst =
@@ -799,6 +820,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
     __amdgpu_buffer_rsrc_t rX;
     if (XDMA) rX = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (unsigned)((long)g.N * g.in_ss * 2), 0x00020000);
     auto dma_halo = [&](int ph) {
+      if (RX_ABLATE(g, 1)) return;
       const int tile = t_begin + ph / ppt, cc = (ph % ppt) / 3;
       int n, z0, y0, x0;
       tile_origin(tile, n, z0, y0, x0);
@@ -997,13 +1019,13 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
           for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
       for (int cc = 0; cc < nchunks; ++cc) {
         const unsigned xbase = sX_base + ((ph / 3) & 1) * CH64_X_BYTES;
-        plane(std::integral_constant<int, 0>{}, sW_base + (ph & 1) * CH64_W_BYTES, xbase);
+        if (!RX_ABLATE(g, 4)) plane(std::integral_constant<int, 0>{}, sW_base + (ph & 1) * CH64_W_BYTES, xbase);
         lds_only_barrier();
         ++ph;
-        plane(std::integral_constant<int, 1>{}, sW_base + (ph & 1) * CH64_W_BYTES, xbase);
+        if (!RX_ABLATE(g, 4)) plane(std::integral_constant<int, 1>{}, sW_base + (ph & 1) * CH64_W_BYTES, xbase);
         lds_only_barrier();
         ++ph;
-        plane(std::integral_constant<int, 2>{}, sW_base + (ph & 1) * CH64_W_BYTES, xbase);
+        if (!RX_ABLATE(g, 4)) plane(std::integral_constant<int, 2>{}, sW_base + (ph & 1) * CH64_W_BYTES, xbase);
         if (cc + 1 < nchunks) {
           lds_only_barrier();
           ++ph;
@@ -1016,30 +1038,36 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
       for (int b = 0; b < 2; ++b) {
         const int v = (wave * 2 + b) * 32 + fv;
         const int z = z0 + (v >> 6), y = y0 + ((v >> 4) & 3), x = x0 + (v & 15);
-        if (z >= g.Z || y >= g.Y || x >= g.X) continue;
+        if (z >= g.Z || y >= g.Y || x >= g.X || RX_ABLATE(g, 8)) continue;
         T* op = out + (long)n * g.out_ss + ((long)(z * g.Y + y) * g.X + x) * g.ldo + n0;
+        auto epi = [&](auto HB, auto RA) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+          for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const int co = a * 32 + 8 * g4 + 4 * fh;
-            const long cm = a * g.out_cs + 8 * g4 + 4 * fh;    // memory offset of channel co (== co unless out is a planar concat)
-            T vals[4];
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const int co = a * 32 + 8 * g4 + 4 * fh;
+              const long cm = a * g.out_cs + 8 * g4 + 4 * fh;    // memory offset of channel co (== co unless out is a planar concat)
+              f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+              if (decltype(HB)::value) bv = *reinterpret_cast<const f32x4*>(bias + n0 + co);
+              u32x2 old2 = {0u, 0u};
+              if (!ACC && decltype(RA)::value) old2 = *reinterpret_cast<const u32x2*>(op + cm);
+              T vals[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              float f = acc[a][b][4 * g4 + i];
-              if (bias) f += bias[n0 + co + i];
-              if (ACC) f += Elem<T>::to_f(reinterpret_cast<const T*>(&oldv[a][b][g4])[i]);
-              else if (g.accumulate) f += Elem<T>::to_f(op[cm + i]);
-              vals[i] = Elem<T>::from_f(f);
-              if (STATS) {
-                const float r = Elem<T>::to_f(vals[i]);
-                s1[a][4 * g4 + i] += r;
-                s2[a][4 * g4 + i] += r * r;
+              for (int i = 0; i < 4; ++i) {
+                float f = acc[a][b][4 * g4 + i] + bv[i];
+                if (ACC) f += Elem<T>::to_f(reinterpret_cast<const T*>(&oldv[a][b][g4])[i]);
+                else if (decltype(RA)::value) f += Elem<T>::to_f(reinterpret_cast<const T*>(&old2)[i]);
+                vals[i] = Elem<T>::from_f(f);
+                if (STATS) {
+                  const float r = Elem<T>::to_f(vals[i]);
+                  s1[a][4 * g4 + i] += r;
+                  s2[a][4 * g4 + i] += r * r;
+                }
               }
+              if (!RX_ABLATE(g, 16) || vals[0] == (T)12345.f) *reinterpret_cast<u32x2*>(op + cm) = *reinterpret_cast<u32x2*>(vals);
             }
-            *reinterpret_cast<u32x2*>(op + cm) = *reinterpret_cast<u32x2*>(vals);
-          }
+        };
+        RX_EPI_DISPATCH(bias != nullptr, !ACC && g.accumulate != 0, epi);
       }
       lds_only_barrier();
       ++ph;

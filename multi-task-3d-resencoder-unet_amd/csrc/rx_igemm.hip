@@ -171,24 +171,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ in, co
     int qy = t % P_.Qy, qz = t / P_.Qy;
     long ov = ((long)(qz * g.osz + P_.opz) * g.Yo + (qy * g.osy + P_.opy)) * g.Xo + (qx * g.osx + P_.opx);
     T* op = out + (long)n * g.out_ss + ov * g.ldo + n0;
+    auto epi = [&](auto HB, auto RA) {       // bias / accumulate as compile-time flags behind one uniform branch (RX_EPI_DISPATCH)
 #pragma unroll
-    for (int a = 0; a < NB; ++a)
+      for (int a = 0; a < NB; ++a)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int co = a * 32 + 8 * g4 + 4 * fh;
-        T vals[4];
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int co = a * 32 + 8 * g4 + 4 * fh;
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+          if (decltype(HB)::value) bv = *reinterpret_cast<const f32x4*>(bias + n0 + co);
+          T old4[4];
+          if (decltype(RA)::value) {
+            if (sizeof(T) == 2) *reinterpret_cast<u32x2*>(old4) = *reinterpret_cast<const u32x2*>(op + co);
+            else *reinterpret_cast<u32x4*>(old4) = *reinterpret_cast<const u32x4*>(op + co);
+          }
+          T vals[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float f = acc[a][b][4 * g4 + i];
-          if (bias) f += bias[n0 + co + i];
-          if (g.accumulate) f += Elem<T>::to_f(op[co + i]);
-          vals[i] = Elem<T>::from_f(f);
+          for (int i = 0; i < 4; ++i) {
+            float f = acc[a][b][4 * g4 + i] + bv[i];
+            if (decltype(RA)::value) f += Elem<T>::to_f(old4[i]);
+            vals[i] = Elem<T>::from_f(f);
+          }
+          if (sizeof(T) == 2)
+            *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
+          else
+            *reinterpret_cast<u32x4*>(op + co) = *reinterpret_cast<u32x4*>(vals);
         }
-        if (sizeof(T) == 2)
-          *reinterpret_cast<u32x2*>(op + co) = *reinterpret_cast<u32x2*>(vals);
-        else
-          *reinterpret_cast<u32x4*>(op + co) = *reinterpret_cast<u32x4*>(vals);
-      }
+    };
+    RX_EPI_DISPATCH(bias != nullptr, g.accumulate != 0, epi);
   }
 }
 
