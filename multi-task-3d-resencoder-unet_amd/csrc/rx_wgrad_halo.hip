@@ -679,6 +679,14 @@ static int wgh_plan(const rx_act* x, const rx_act* dy, const int32_t stride[3], 
   // slab traffic and reduce work of 512); the generic kernel runs two per CU
   long target = (!strided && TZ == 4 && TY == 4 && TX == 16 && !getenv("RX_WGH_S512")) ? 256 : 512;
   if (target == 256 && g->NT * PP < 16 * 256) target = 512;   // few tiles (16^3 layers): shorter per-workgroup chains win
+  {
+    static long tgt_env = -1;   // RX_WGH_TARGET: workgroups aimed at by the split choice of the generic-tile kernel (experiments)
+    if (tgt_env < 0) {
+      const char* e = getenv("RX_WGH_TARGET");
+      tgt_env = e ? atol(e) : 0;
+    }
+    if (tgt_env > 0 && target == 512) target = tgt_env;
+  }
   long S = (target + PP - 1) / PP;
   if (PP >= 256) S = 1;  // the panel pairs alone fill the chip: accumulate every tile in registers, write dw directly
   if (S > g->NT) S = g->NT;

@@ -14,6 +14,8 @@ SHAPES = [  # name, ci, co, dims, batch
     ("128->64@64", 128, 64, (64, 64, 64), 2),
     ("128->128@32", 128, 128, (32, 32, 32), 2),
     ("256->256@16", 256, 256, (16, 16, 16), 2),
+    ("320->320@8", 320, 320, (8, 8, 8), 2),
+    ("320->320@4", 320, 320, (4, 4, 4), 2),
     ("512->512@8", 512, 512, (8, 8, 8), 2),
     ("512->512@4", 512, 512, (4, 4, 4), 2),
 ]
