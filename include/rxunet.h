@@ -205,6 +205,11 @@ int rx_avgpool_bwd(rx_dtype dt, const rx_act* dy, const rx_act* dx, const int32_
  *      for Cin <= 4, VALU kernels with all weights in LDS above) ---- */
 int rx_stem_conv_fwd(rx_dtype dt, const float* x_ncdhw, int n, int cin, int z, int y, int x, const float* w,
                      const float* bias, const rx_act* out, const int32_t kernel[3], void* stream);
+/* rx_stem_conv_fwd followed by rx_instnorm_stats of its output (workspace: rx_instnorm_stats_workspace(out)); on the MFMA
+ * kernel the statistics come out of the same pass.  Same (mean, rstd) either way. */
+int rx_stem_conv_fwd_stats(rx_dtype dt, const float* x_ncdhw, int n, int cin, int z, int y, int x, const float* w,
+                           const float* bias, const rx_act* out, const int32_t kernel[3], float eps, float* stats,
+                           void* ws, size_t ws_bytes, void* stream);
 size_t rx_stem_conv_bwd_weight_workspace(int cin, int cout, int taps);
 int rx_stem_conv_bwd_weight(rx_dtype dt, const float* x_ncdhw, int n, int cin, int z, int y, int x,
                             const rx_act* dy, float* dw, const int32_t kernel[3], void* ws, size_t ws_bytes,

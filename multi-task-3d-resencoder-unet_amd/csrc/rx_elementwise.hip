@@ -713,7 +713,7 @@ extern "C" int rx_instnorm_act_bwd(rx_dtype dt, const rx_act* g, const rx_act* y
   if (V <= RX_IN_SMALL_MAX_VOXELS && C % 32 == 0) {   // low-resolution stages: one launch instead of three
     hipStream_t st1 = (hipStream_t)stream;
     const int mode = use_mask ? 1 : (mask_xhat ? 2 : 0);
-    const bool narrow = V >= rx_in_small_narrow();
+    const bool narrow = dt != RX_F32 && V >= rx_in_small_narrow();   // (fp32 = parity mode: the summation order the goldens' seeds were screened with)
     dim3 grid1(narrow ? C / 8 : C / 32, N);
 #define RX_LAUNCH_IN_SMALL_BWD(G)                                                                                                     \
   hipLaunchKernelGGL((in_small_bwd_kernel<T, G>), grid1, dim3(256), 0, st1, (const T*)g->ptr, g->ld, V * g->ld, (const T*)y->ptr, y->ld, \
@@ -948,7 +948,7 @@ extern "C" int rx_instnorm_fwd(rx_dtype dt, const rx_act* y, float eps, float* s
     if (!same_geom(y, residual)) RX_FAIL(RX_EINVAL, "rx_instnorm_fwd: residual geometry mismatch");
   }
   hipStream_t st = (hipStream_t)stream;
-  const bool narrow = V >= rx_in_small_narrow();
+  const bool narrow = dt != RX_F32 && V >= rx_in_small_narrow();   // (fp32 = parity mode: the summation order the goldens' seeds were screened with)
   dim3 grid(narrow ? y->c / 8 : y->c / 32, y->n);
 #define RX_LAUNCH_IN_SMALL_FWD(G, RES)                                                                                              \
   hipLaunchKernelGGL((in_small_fwd_kernel<T, G, RES>), grid, dim3(256), 0, st, (const T*)y->ptr, y->ld, V * y->ld,                  \
@@ -1818,7 +1818,47 @@ static int check_kernel13(const int32_t k[3], const char* who) {
 }
 
 int rx_stem_fwd_mfma_try(rx_dtype dt, const float* x, int n, int cin, int z, int y, int xx, const float* w, const float* bias,
-                         const rx_act* out, const int32_t kernel[3], hipStream_t st);
+                         const rx_act* out, const int32_t kernel[3], hipStream_t st, float* stat_part, size_t stat_bytes, int* stat_chunks);
+static int rx_stem_mfma_on() {
+  static int mf = -1;      // RX_STEM_MFMA=0: the VALU kernels
+  if (mf < 0) {
+    const char* e = getenv("RX_STEM_MFMA");
+    mf = e ? atoi(e) : 1;
+  }
+  return mf;
+}
+
+// the stem conv and the InstanceNorm statistics of its output (encoder.py:84 + simple_conv_blocks.py:58-72): one pass on the
+// MFMA kernel (the separate statistics pass read the 268 MB output of the cfg2 stem again: 109 us of a 17 ms step), the two
+// calls otherwise.  Same statistics either way (sums of the values as stored).
+extern "C" int rx_stem_conv_fwd_stats(rx_dtype dt, const float* x_ncdhw, int n, int cin, int z, int y, int x, const float* w,
+                                      const float* bias, const rx_act* out, const int32_t kernel[3], float eps, float* stats, void* ws,
+                                      size_t ws_bytes, void* stream) {
+  RX_RECORD(stream, [=, out_ = RxActV(out), kernel_ = RxI3V(kernel)](void* s) { return rx_stem_conv_fwd_stats(dt, x_ncdhw, n, cin, z, y, x, w, bias, out_.p(), kernel_.v, eps, stats, ws, ws_bytes, s); });
+  int rc;
+  if ((rc = check_vec_channels(out, dt, "rx_stem_conv_fwd_stats(out)"))) return rc;
+  if ((rc = check_kernel13(kernel, "rx_stem_conv_fwd_stats"))) return rc;
+  if (!x_ncdhw || !w || !stats || !ws || cin < 1 || cin > 16) RX_FAIL(RX_EINVAL, "rx_stem_conv_fwd_stats: bad arguments");
+  if (out->n != n || out->z != z || out->y != y || out->x != x) RX_FAIL(RX_EINVAL, "rx_stem_conv_fwd_stats: geometry mismatch");
+  static int fuse = -1;
+  if (fuse < 0) {
+    const char* e = getenv("RX_FUSED_STATS");
+    fuse = e ? atoi(e) : 1;
+  }
+  int chunks = 0;
+  if (fuse && rx_stem_mfma_on() &&
+      rx_stem_fwd_mfma_try(dt, x_ncdhw, n, cin, z, y, x, w, bias, out, kernel, (hipStream_t)stream, (float*)ws, ws_bytes, &chunks) == 1) {
+    if (chunks > 0) {
+      rx_stats_finalize_launch((const float*)ws, n, chunks, out->c, (double)rx_act_voxels(out), eps, stats, (hipStream_t)stream);
+      RX_CHECK_LAUNCH("rx_stem_conv_fwd_stats");
+      return RX_OK;
+    }
+    RX_CHECK_LAUNCH("rx_stem_conv_fwd_stats(mfma)");
+    return rx_instnorm_stats(dt, out, eps, stats, ws, ws_bytes, stream);
+  }
+  if ((rc = rx_stem_conv_fwd(dt, x_ncdhw, n, cin, z, y, x, w, bias, out, kernel, stream))) return rc;
+  return rx_instnorm_stats(dt, out, eps, stats, ws, ws_bytes, stream);
+}
 
 extern "C" int rx_stem_conv_fwd(rx_dtype dt, const float* x_ncdhw, int n, int cin, int z, int y, int x, const float* w,
                                 const float* bias, const rx_act* out, const int32_t kernel[3], void* stream) {
@@ -1841,16 +1881,9 @@ extern "C" int rx_stem_conv_fwd(rx_dtype dt, const float* x_ncdhw, int n, int ci
   if (out->n != n || out->z != z || out->y != y || out->x != x) RX_FAIL(RX_EINVAL, "rx_stem_conv_fwd: geometry mismatch");
   hipStream_t st = (hipStream_t)stream;
   const int TT = kernel[0] * kernel[1] * kernel[2];
-  {
-    static int mf = -1;      // RX_STEM_MFMA=0: the VALU kernels below
-    if (mf < 0) {
-      const char* e = getenv("RX_STEM_MFMA");
-      mf = e ? atoi(e) : 1;
-    }
-    if (mf && rx_stem_fwd_mfma_try(dt, x_ncdhw, n, cin, z, y, x, w, bias, out, kernel, st) == 1) {
-      RX_CHECK_LAUNCH("rx_stem_conv_fwd(mfma)");
-      return RX_OK;
-    }
+  if (rx_stem_mfma_on() && rx_stem_fwd_mfma_try(dt, x_ncdhw, n, cin, z, y, x, w, bias, out, kernel, st, nullptr, 0, nullptr) == 1) {
+    RX_CHECK_LAUNCH("rx_stem_conv_fwd(mfma)");
+    return RX_OK;
   }
   if (dt != RX_F32 && out->c % 32 == 0 && (out->c * 4) % 16 == 0 && !getenv("RX_NO_STEM32")) {   // one thread per voxel x 32 channels
     const long V = rx_act_voxels(out);

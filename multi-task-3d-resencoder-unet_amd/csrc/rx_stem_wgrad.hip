@@ -187,10 +187,14 @@ int rx_stem_wgrad_mfma_try(rx_dtype dt, const float* x, int n, int cin, int z, i
 // gathered from the fp32 halo tile in LDS (tap offsets from a small LDS table) and converted in registers.  Tile 4x4x16.
 // ---------------------------------------------------------------------------------------------------------------------
 #define RX_STEM_NOTAP 0x40000000
-template <typename T>
+// STATS: the InstanceNorm statistics of the output come out of the same pass (running per-lane sums of the values as stored,
+// one partial row per wave at the end -- ch_stat_flush, rx_common.h); a block's tile range then never straddles samples
+// (blocks_per_sample blocks each).
+template <typename T, bool STATS = false>
 __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restrict__ x, int Cin, int N, int Z, int Y, int X,
                                                             const float* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
-                                                            int ldo, long so, int kz, int ky, int kx, int tiles_per_block) {
+                                                            int ldo, long so, int kz, int ky, int kx, int tiles_per_block,
+                                                            int blocks_per_sample = 0, float* __restrict__ stat_part = nullptr) {
   constexpr int TZ = 4, TY = 4, TX = 16, HY = TY + 2, HX = TX + 2, HV = (TZ + 2) * HY * HX;  // 648
   constexpr int XP = (HV + 255) / 256;
   __shared__ float sX[4][HV + 8];
@@ -200,7 +204,17 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
   const int pz = (kz - 1) / 2, py = (ky - 1) / 2, px = (kx - 1) / 2;
   const int tz_n = (Z + TZ - 1) / TZ, ty_n = (Y + TY - 1) / TY, tx_n = (X + TX - 1) / TX;
   const int NT = N * tz_n * ty_n * tx_n;
-  const int t_begin = blockIdx.x * tiles_per_block, t_end = min(NT, t_begin + tiles_per_block);
+  int t_begin = blockIdx.x * tiles_per_block, t_end = min(NT, t_begin + tiles_per_block);
+  const int sn = STATS ? blockIdx.x / blocks_per_sample : 0, sl = STATS ? blockIdx.x - sn * blocks_per_sample : 0;
+  if (STATS) {
+    const int NTs = NT / N;
+    t_begin = sn * NTs + sl * tiles_per_block, t_end = min((sn + 1) * NTs, t_begin + tiles_per_block);
+  }
+  float s1[1][16], s2[1][16];
+  if (STATS) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s1[0][r] = 0.f, s2[0][r] = 0.f;
+  }
   const long V = (long)Z * Y * X;
   if (tid < 128) {
     int o = RX_STEM_NOTAP;
@@ -293,16 +307,26 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
       for (int g4 = 0; g4 < 4; ++g4) {
         T vals[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) vals[i] = Elem<T>::from_f(acc[4 * g4 + i]);
+        for (int i = 0; i < 4; ++i) {
+          vals[i] = Elem<T>::from_f(acc[4 * g4 + i]);
+          if (STATS) {
+            const float r = Elem<T>::to_f(vals[i]);
+            s1[0][4 * g4 + i] += r;
+            s2[0][4 * g4 + i] += r * r;
+          }
+        }
         *reinterpret_cast<u32x2*>(op + 8 * g4 + 4 * fh) = *reinterpret_cast<u32x2*>(vals);
       }
     }
   }
+  if (STATS) ch_stat_flush<1>(s1, s2, stat_part, sn, blocks_per_sample * 4, sl * 4 + wave, 32, 0, lane);
 }
 
-// returns 1 if handled (16-bit dtypes, Cout == 32, Cin * taps <= 112), 0 otherwise
+// returns 1 if handled (16-bit dtypes, Cout == 32, Cin * taps <= 112), 0 otherwise.  stat_part (optional, stat_bytes large):
+// per-wave partial sums of y and y^2 are left there ([n][*stat_chunks][2][32] floats) and *stat_chunks > 0
 int rx_stem_fwd_mfma_try(rx_dtype dt, const float* x, int n, int cin, int z, int y, int xx, const float* w, const float* bias,
-                         const rx_act* out, const int32_t kernel[3], hipStream_t st) {
+                         const rx_act* out, const int32_t kernel[3], hipStream_t st, float* stat_part, size_t stat_bytes, int* stat_chunks) {
+  if (stat_chunks) *stat_chunks = 0;
   const int K = cin * kernel[0] * kernel[1] * kernel[2];
   // (the kernel stages at most 4 input channels: with 5-8 of them a small kernel -- K = Cin * taps <= 112 -- used to be accepted
   // here and computed garbage; found by tests/test_fuzz_gpu.py)
@@ -314,14 +338,26 @@ int rx_stem_fwd_mfma_try(rx_dtype dt, const float* x, int n, int cin, int z, int
     maxb = e ? atoi(e) : 1024;   // measured: 512 -> 162 us, 768 -> 131, 1024 -> 119, 1280 -> 147, 2048 -> 127, one tile per workgroup -> 193
   }
   int blocks = NT < maxb ? NT : maxb;       // 4 resident workgroups per CU, the weights / tap table are set up once per workgroup
-  const int per = (NT + blocks - 1) / blocks;
+  int per = (NT + blocks - 1) / blocks;
   blocks = (NT + per - 1) / per;
   const long so = rx_act_voxels(out) * (long)out->ld;
-  if (dt == RX_BF16)
-    hipLaunchKernelGGL((stem_fwd_mfma_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, x, cin, n, z, y, xx, w, bias, (bf16_t*)out->ptr, out->ld, so,
-                       kernel[0], kernel[1], kernel[2], per);
-  else
-    hipLaunchKernelGGL((stem_fwd_mfma_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, x, cin, n, z, y, xx, w, bias, (f16_t*)out->ptr, out->ld, so,
-                       kernel[0], kernel[1], kernel[2], per);
+  const int NTs = NT / n;
+  int bps = blocks / n > 0 ? blocks / n : 1;                 // statistics: whole blocks per sample
+  const int per_s = (NTs + bps - 1) / bps;
+  bps = (NTs + per_s - 1) / per_s;
+  const bool stats = stat_part && stat_chunks && (size_t)n * bps * 4 * 2 * 32 * sizeof(float) <= stat_bytes;
+#define RX_STEM_FWD(TT)                                                                                                                \
+  do {                                                                                                                                 \
+    if (stats)                                                                                                                         \
+      hipLaunchKernelGGL((stem_fwd_mfma_kernel<TT, true>), dim3(bps * n), dim3(256), 0, st, x, cin, n, z, y, xx, w, bias, (TT*)out->ptr, \
+                         out->ld, so, kernel[0], kernel[1], kernel[2], per_s, bps, stat_part);                                         \
+    else                                                                                                                               \
+      hipLaunchKernelGGL((stem_fwd_mfma_kernel<TT, false>), dim3(blocks), dim3(256), 0, st, x, cin, n, z, y, xx, w, bias,              \
+                         (TT*)out->ptr, out->ld, so, kernel[0], kernel[1], kernel[2], per, 0, (float*)nullptr);                        \
+  } while (0)
+  if (dt == RX_BF16) RX_STEM_FWD(bf16_t);
+  else RX_STEM_FWD(f16_t);
+#undef RX_STEM_FWD
+  if (stats) *stat_chunks = bps * 4;
   return 1;
 }

@@ -77,6 +77,8 @@ _SIGNATURES = {
     "rx_avgpool_bwd": (c_int, [c_int, _P, _P, I3, c_int, c_void_p]),
     "rx_stem_conv_fwd": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, _P, I3,
                                  c_void_p]),
+    "rx_stem_conv_fwd_stats": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, _P, I3,
+                                       c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rx_stem_conv_bwd_weight_workspace": (c_size_t, [c_int, c_int, c_int]),
     "rx_stem_conv_bwd_weight": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, _P, c_void_p, I3,
                                         c_void_p, c_size_t, c_void_p]),

@@ -526,6 +526,16 @@ def stem_conv_fwd(x_ncdhw, w, bias, out, kernel):
                                   byref(out.desc()), I3(*kernel), stream_ptr()), "rx_stem_conv_fwd")
 
 
+def stem_conv_fwd_stats(x_ncdhw, w, bias, out, kernel, stats, eps=1e-5, ws=None):
+    """stem conv + InstanceNorm statistics of its output (one pass on the MFMA kernel)"""
+    n, cin, z, y, x = x_ncdhw.shape
+    assert x_ncdhw.dtype == torch.float32 and x_ncdhw.is_contiguous()
+    ws = workspace() if ws is None else ws
+    check(load().rx_stem_conv_fwd_stats(_code(out.dtype), _ptr(x_ncdhw), n, cin, z, y, x, _ptr(w), _ptr(bias),
+                                        byref(out.desc()), I3(*kernel), float(eps), _ptr(stats), *_ws_args(ws), stream_ptr()),
+          "rx_stem_conv_fwd_stats")
+
+
 def stem_conv_bwd_weight(x_ncdhw, dy, dw, kernel, ws=None):
     n, cin, z, y, x = x_ncdhw.shape
     need = load().rx_stem_conv_bwd_weight_workspace(cin, dy.c, 27)
@@ -684,6 +694,7 @@ channel_sum = _hbm("channel_sum", lambda x, out, ws=None: _tb(x))(channel_sum)
 pack_conv_weight = _hbm("pack", _pack_bytes)(pack_conv_weight)
 pack_convT_weight = _hbm("pack", _pack_bytes)(pack_convT_weight)
 stem_conv_fwd = _hbm("stem_conv_fwd", lambda x_ncdhw, w, bias, out, kernel: x_ncdhw.numel() * 4 + _tb(out))(stem_conv_fwd)
+stem_conv_fwd_stats = _hbm("stem_conv_fwd", lambda x_ncdhw, w, bias, out, kernel, stats, eps=1e-5, ws=None: x_ncdhw.numel() * 4 + _tb(out))(stem_conv_fwd_stats)
 stem_conv_bwd_weight = _hbm("stem_conv_bwd_weight", lambda x_ncdhw, dy, dw, kernel, ws=None: x_ncdhw.numel() * 4 + _tb(dy))(stem_conv_bwd_weight)
 convT3d_fwd = _hbm("convT_fwd", lambda x, w_fwd, bias, y, stride, ws=None: _tb(x) + _tb(y))(convT3d_fwd)
 convT3d_bwd_data = _hbm("convT_bwd_data", lambda dy, w_bwd, dx, stride, accumulate=False, ws=None:

@@ -632,6 +632,10 @@ class Plan:
                         and rec.a["y"].act.voxels > 512 and rec.a["y"].act.dims[3] >= 16):
                     rec.a["stats_to"] = nxt.a
                     nxt.a["stats_done"] = True
+                if (rec.kind == "stem" and nxt.kind == "inact" and nxt.a["y"] is rec.a["y"] and self.dtype != torch.float32
+                        and rec.a["y"].act.voxels > 512 and os.environ.get("RX_FUSED_STEM_STATS", "1") != "0"):      # rx_stem_conv_fwd_stats
+                    rec.a["stats_to"] = nxt.a
+                    nxt.a["stats_done"] = True
             # block output -> AvgPool of the next block's skip path: one pass (rx_instnorm_act_pool_fwd) above the size the
             # single-launch InstanceNorm kernel takes
             producers = {id(r.a["out"]): r for r in tape if r.kind == "inact" and r.a["gate"] is None}
@@ -663,7 +667,14 @@ class Plan:
                         and rec.a["y"].act.voxels < self.spatial[0] * self.spatial[1] * self.spatial[2]):
                     self._pack_delay_at = len(f)          # the first layer below full resolution
                 if rec.kind == "stem":
-                    f.append(lambda a=a: ops.stem_conv_fwd(P._x, a["w"], a["b"], a["y"].act, a["kernel"]))
+                    def sstep(a=a):
+                        st = a.get("stats_to")
+                        if st is not None:
+                            ops.stem_conv_fwd_stats(P._x, a["w"], a["b"], a["y"].act, a["kernel"], st["stats"], P._eps_now(st))
+                            P._mask_dropped(st)
+                        else:
+                            ops.stem_conv_fwd(P._x, a["w"], a["b"], a["y"].act, a["kernel"])
+                    f.append(sstep)
                 elif rec.kind == "image":        # NCDHW fp32 image -> channels-last compute type (identity 1x1x1 first-layer conv)
                     f.append(lambda a=a: ops.stem_conv_fwd(P._x, a["w"], None, a["y"].act, [1, 1, 1]))
                 elif rec.kind == "conv":

@@ -307,6 +307,17 @@ def test_stem(ops, dtype, cin, k):
     oa = ops.Act.zeros(n, *dims, co, dtype)
     ops.stem_conv_fwd(xd, w.float().cuda(), b.float().cuda(), oa, k)
     assert rel(oa.to_ncdhw(), ref.detach()) < TOL[dtype]
+    # conv + InstanceNorm statistics in one call (one pass on the MFMA kernel, the two calls elsewhere): the same output bits,
+    # (mean, rstd) of the values as stored
+    ob = ops.Act.zeros(n, *dims, co, dtype)
+    st_f, st_s = torch.zeros((n, co, 2), device="cuda"), torch.zeros((n, co, 2), device="cuda")
+    ops.stem_conv_fwd_stats(xd, w.float().cuda(), b.float().cuda(), ob, k, st_f)
+    assert torch.equal(ob.tensor(), oa.tensor())
+    ops.instnorm_stats(oa, st_s)
+    yv = oa.to_ncdhw().double().cpu()
+    mean, var = yv.mean(dim=(2, 3, 4)), yv.var(dim=(2, 3, 4), unbiased=False)
+    for st in (st_f, st_s):
+        assert rel(st[..., 0].cpu().double(), mean) < 1e-5 and rel(st[..., 1].cpu().double(), (var + 1e-5).rsqrt()) < 1e-5
     dw = torch.empty((co, cin, *k), dtype=torch.float32, device="cuda")
     ops.stem_conv_bwd_weight(xd, to_act(ops, g, dtype), dw, k)
     # 16-bit modes run the MFMA kernel, which rounds the image to the compute dtype (fp32 mode stays exact)
