@@ -190,7 +190,9 @@ int rx_stem_wgrad_mfma_try(rx_dtype dt, const float* x, int n, int cin, int z, i
 // STATS: the InstanceNorm statistics of the output come out of the same pass (running per-lane sums of the values as stored,
 // one partial row per wave at the end -- ch_stat_flush, rx_common.h); a block's tile range then never straddles samples
 // (blocks_per_sample blocks each).
-template <typename T, bool STATS = false>
+// KSM: compile-time bound on the 16-wide k-steps (2 for Cin * taps <= 32 -- one input channel, 3x3x3 -- else 7): the weight
+// fragments are registers, and with 7 of them the STATS variant fell from 4 to 3 resident workgroups per CU (219 us vs 134).
+template <typename T, bool STATS = false, int KSM = 7>
 __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restrict__ x, int Cin, int N, int Z, int Y, int X,
                                                             const float* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
                                                             int ldo, long so, int kz, int ky, int kx, int tiles_per_block,
@@ -235,9 +237,9 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
   }
   // A fragments: lane (co = lane & 31, k-half = lane >> 5) holds W[co][ks*16 + 8*h .. +7]   (w is (32, Cin, TT) = [co][k])
   const int fr = lane & 31, fh = lane >> 5;
-  u32x4 af[7];
+  u32x4 af[KSM];
 #pragma unroll
-  for (int ks = 0; ks < 7; ++ks) {
+  for (int ks = 0; ks < KSM; ++ks) {
     float f[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = bv[r];
 #pragma unroll
-      for (int ks = 0; ks < 7; ++ks) {
+      for (int ks = 0; ks < KSM; ++ks) {
         if (ks < KS) {
           float f[8];
 #pragma unroll
@@ -346,17 +348,22 @@ int rx_stem_fwd_mfma_try(rx_dtype dt, const float* x, int n, int cin, int z, int
   const int per_s = (NTs + bps - 1) / bps;
   bps = (NTs + per_s - 1) / per_s;
   const bool stats = stat_part && stat_chunks && (size_t)n * bps * 4 * 2 * 32 * sizeof(float) <= stat_bytes;
-#define RX_STEM_FWD(TT)                                                                                                                \
+#define RX_STEM_FWD(TT, KSM)                                                                                                           \
   do {                                                                                                                                 \
     if (stats)                                                                                                                         \
-      hipLaunchKernelGGL((stem_fwd_mfma_kernel<TT, true>), dim3(bps * n), dim3(256), 0, st, x, cin, n, z, y, xx, w, bias, (TT*)out->ptr, \
-                         out->ld, so, kernel[0], kernel[1], kernel[2], per_s, bps, stat_part);                                         \
+      hipLaunchKernelGGL((stem_fwd_mfma_kernel<TT, true, KSM>), dim3(bps * n), dim3(256), 0, st, x, cin, n, z, y, xx, w, bias,         \
+                         (TT*)out->ptr, out->ld, so, kernel[0], kernel[1], kernel[2], per_s, bps, stat_part);                          \
     else                                                                                                                               \
-      hipLaunchKernelGGL((stem_fwd_mfma_kernel<TT, false>), dim3(blocks), dim3(256), 0, st, x, cin, n, z, y, xx, w, bias,              \
+      hipLaunchKernelGGL((stem_fwd_mfma_kernel<TT, false, KSM>), dim3(blocks), dim3(256), 0, st, x, cin, n, z, y, xx, w, bias,         \
                          (TT*)out->ptr, out->ld, so, kernel[0], kernel[1], kernel[2], per, 0, (float*)nullptr);                        \
   } while (0)
-  if (dt == RX_BF16) RX_STEM_FWD(bf16_t);
-  else RX_STEM_FWD(f16_t);
+  if (dt == RX_BF16) {
+    if (K <= 32) RX_STEM_FWD(bf16_t, 2);
+    else RX_STEM_FWD(bf16_t, 7);
+  } else {
+    if (K <= 32) RX_STEM_FWD(f16_t, 2);
+    else RX_STEM_FWD(f16_t, 7);
+  }
 #undef RX_STEM_FWD
   if (stats) *stat_chunks = bps * 4;
   return 1;
