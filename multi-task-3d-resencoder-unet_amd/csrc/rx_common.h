@@ -73,43 +73,6 @@ struct RxBwdStat {
 // are not free in these kernels (DESIGN §8 row y), so the production build folds them away.
 #ifndef RX_ABLATION
 #define RX_ABLATION 0
-// ---- InstanceNorm statistics in the conv epilogue (persistent kernels, forward) --------------------------------------
-// A consumer lane owns the same 16 (or 2 x 16) output channels for every voxel of every tile its workgroup walks, so the
-// per-(n, c) sums of y and y^2 are RUNNING per-lane sums over the workgroup's whole life (2 VALU per stored value) and the
-// cross-lane step -- a 5-step xor-shuffle over the 32 lanes of a half-wave, which own the same channels -- happens ONCE per
-// workgroup, not per tile (round 1 rejected the per-tile version: ~320 shuffles per wave and tile).  Sums are taken of the
-// values as STORED (rounded to the compute dtype): identical statistics to the separate pass over y.  Each consumer wave
-// writes its own partial row; layout as colreduce_kernel's: part[((n*nchunks + chunk)*2 + a)*Co + c], chunk = wg*4 + wave.
-template <int NA>
-__device__ inline void ch_stat_flush(float (&s1)[NA][16], float (&s2)[NA][16], float* __restrict__ part, int n, int nchunks, int chunk, int Co,
-                                     int n0, int lane) {
-#pragma unroll
-  for (int a = 0; a < NA; ++a)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float u = s1[a][r], v = s2[a][r];
-#pragma unroll
-      for (int o = 1; o < 32; o <<= 1) {
-        u += __shfl_xor(u, o, 64);
-        v += __shfl_xor(v, o, 64);
-      }
-      s1[a][r] = u, s2[a][r] = v;
-    }
-  if ((lane & 31) == 0) {
-    const int fh = lane >> 5;
-    float* p0 = part + ((size_t)(n * nchunks + chunk) * 2) * Co + n0;
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = a * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
-        p0[co] = s1[a][r];
-        p0[Co + co] = s2[a][r];
-      }
-  }
-}
-
-
 #endif
 #define RX_ABLATE(g, bit) (RX_ABLATION && ((g).dbg & (bit)))
 
@@ -292,5 +255,41 @@ __device__ __forceinline__ void rx_tile_coords(int t, int tx_n, int ty_n, int tz
     int c = t / tx_n;
     ty = c % ty_n, c /= ty_n;
     tz = c % tz_n, n = c / tz_n;
+  }
+}
+
+// ---- InstanceNorm statistics in the conv epilogue (persistent kernels, forward) --------------------------------------
+// A consumer lane owns the same 16 (or 2 x 16) output channels for every voxel of every tile its workgroup walks, so the
+// per-(n, c) sums of y and y^2 are RUNNING per-lane sums over the workgroup's whole life (2 VALU per stored value) and the
+// cross-lane step -- a 5-step xor-shuffle over the 32 lanes of a half-wave, which own the same channels -- happens ONCE per
+// workgroup, not per tile (round 1 rejected the per-tile version: ~320 shuffles per wave and tile).  Sums are taken of the
+// values as STORED (rounded to the compute dtype): identical statistics to the separate pass over y.  Each consumer wave
+// writes its own partial row; layout as colreduce_kernel's: part[((n*nchunks + chunk)*2 + a)*Co + c], chunk = wg*4 + wave.
+template <int NA>
+__device__ inline void ch_stat_flush(float (&s1)[NA][16], float (&s2)[NA][16], float* __restrict__ part, int n, int nchunks, int chunk, int Co,
+                                     int n0, int lane) {
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float u = s1[a][r], v = s2[a][r];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        u += __shfl_xor(u, o, 64);
+        v += __shfl_xor(v, o, 64);
+      }
+      s1[a][r] = u, s2[a][r] = v;
+    }
+  if ((lane & 31) == 0) {
+    const int fh = lane >> 5;
+    float* p0 = part + ((size_t)(n * nchunks + chunk) * 2) * Co + n0;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = a * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
+        p0[co] = s1[a][r];
+        p0[Co + co] = s2[a][r];
+      }
   }
 }
