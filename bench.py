@@ -218,6 +218,36 @@ def cpu_baseline(workload, timeout_s=300):
                     sample=f"3 {workload} steps at batch 1 did not finish within {timeout_s} s on {threads} threads")
 
 
+def clock_probe(dtype, iters=30):
+    """The dominant kernel ALONE on one of its cfg2 shapes (64 -> 64 channels, 64^3, batch 2), on random and on all-zero operands:
+    MI355X lowers its clock under an MFMA-dense load on random data (MI355X_MICROARCH.md, DVFS give-back), so the same binary is
+    20-38 % faster on zeros.  The ratio says how much of `1 - roofline.frac` is power management rather than kernel structure
+    (the peak in `roofline` is the 2.4 GHz nameplate figure)."""
+    from mt3d_amd.engine import ops, lib as _lib
+    n, c, dims = 2, 64, (64, 64, 64)
+    flops = 2.0 * n * dims[0] * dims[1] * dims[2] * c * c * 27
+    out = {"shape": f"{c}->{c} channels, {dims[0]}^3, batch {n}, 3x3x3 weight gradient", "iters": iters}
+    for label, mk in (("random", torch.randn), ("zeros", torch.zeros), ("random_again", torch.randn)):
+        x = ops.Act(mk((n, *dims, c), device="cuda").to(dtype))
+        dy = ops.Act(mk((n, *dims, c), device="cuda").to(dtype))
+        dw = torch.empty((c, c, 3, 3, 3), device="cuda")
+        fn = lambda: ops.conv3d_bwd_weight(x, dy, dw, (3, 3, 3), (1, 1, 1))
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        out[label] = {"us_per_launch": us, "tflops": flops / us / 1e6}
+        out["kernel"] = _lib.load().rx_last_conv_kernel().decode()
+    out["zeros_over_random"] = out["zeros"]["tflops"] / max(out["random"]["tflops"], out["random_again"]["tflops"])
+    return out
+
+
 def through_trainer(workload, batch, dtype, warmup, steps):
     """the same workload through the reference's plug-in surface: `BaseTrainer` (train.py:19-339 mirror) with its hooks, a
     DataLoader over `SyntheticPatchDataset` (pinned memory, worker processes), torch.compile wrapper, autocast, the engine's AdamW
@@ -563,6 +593,11 @@ def main():
                                                  avg_us_per_launch=isolated[dom_i]["avg_us_per_launch"],
                                                  note="same kernels, weight-gradient stream overlap disabled (2 extra steps)",
                                                  all=isolated)
+        if world == 1 and not args.no_kernel_timing and args.dtype != "fp32":
+            try:
+                line["clock_probe"] = clock_probe(DTYPES[args.dtype])
+            except Exception as e:      # noqa: BLE001 -- a diagnostic must not cost the bench line
+                print(f"[bench] clock probe failed: {e}", file=sys.stderr, flush=True)
         if args.through_trainer and world == 1:
             line["trainer"] = through_trainer(args.workload, batch, args.dtype, args.warmup, args.steps)
         if world == 1 and not args.no_cpu_baseline:

@@ -27,13 +27,16 @@ KINDS = ("fwd", "fwdst", "dgrad", "dgradacc", "wgrad")   # dgradacc: dx += (accu
 kinds = [f for f in flt if f in KINDS] or ["fwd", "dgrad", "wgrad"]
 names = [f for f in flt if f not in KINDS]
 dt = torch.bfloat16
+ZEROS = "--zeros" in sys.argv      # all-zero operands: the chip holds a higher clock (MI355X_MICROARCH.md, DVFS give-back) -- the gap to
+                                   # the random-data figure is power management, not the kernel
 for name, ci, co, dims, n in SHAPES:
     if names and not any(f in name for f in names):
         continue
-    x = ops.Act(torch.randn((n, *dims, ci), device="cuda").to(dt))
-    y = ops.Act(torch.randn((n, *dims, co), device="cuda").to(dt))
+    mk = torch.zeros if ZEROS else torch.randn
+    x = ops.Act(mk((n, *dims, ci), device="cuda").to(dt))
+    y = ops.Act(mk((n, *dims, co), device="cuda").to(dt))
     dx = ops.Act.zeros(n, *dims, ci, dt)
-    w = torch.randn((co, ci, 3, 3, 3), device="cuda") * 0.05
+    w = mk((co, ci, 3, 3, 3), device="cuda") * 0.05
     wf, wb = ops.pack_conv_weight(w, dt)
     dw = torch.empty_like(w)
     k, s = (3, 3, 3), (1, 1, 1)
