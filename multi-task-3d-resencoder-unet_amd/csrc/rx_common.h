@@ -216,24 +216,6 @@ struct Mma<float> {
   }
 };
 
-// one 16x16 accumulator update from two 16-byte operand fragments (lane = row/col (lane&15), k-group (lane>>4): 8 k-values each,
-// K = 32).  Same cycles per FLOP as the 32x32x16 form; MI355X_MICROARCH.md measures it at 1.12-1.15x the FLOP/s on random data
-// (the chip holds a higher clock under this shape).
-template <typename T>
-struct Mma16;
-template <>
-struct Mma16<bf16_t> {
-  __device__ static inline void run(f32x4& c, const u32x4& a, const u32x4& b) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  }
-};
-template <>
-struct Mma16<f16_t> {
-  __device__ static inline void run(f32x4& c, const u32x4& a, const u32x4& b) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  }
-};
-
 // ---- XCD-aware block order ------------------------------------------------------------------------------------------
 // Workgroups are dealt round-robin over the 8 XCDs (observed; a speed assumption only, never correctness), each with its
 // own 4 MiB L2.  Remap the physical linear block id so that every XCD works through one CONTIGUOUS range of logical

@@ -633,204 +633,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo16ws_kernel(const T* __restr
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// wgrad_halo16ws on the 16x16x32 MFMA shape (the >= 32^3 kernels are limited by the clock the chip holds under
-// an MFMA-dense load on random data, and it holds a higher one under this shape).  Same split of the work (4 consumer waves x 7
-// taps, 4 DMA producer waves, two tile buffers, one barrier per tile), same bytes of LDS; what changes is the LDS IMAGE and the
-// fragment geometry:
-//   * a fragment is 16 channels x 32 voxels: lane (kg = lane>>4, q4, p4) reads 8 bytes at voxel row 4 kg + q4 (and 16 rows on),
-//     channel group 4 p4 of a 16-channel HALF.  With 64-byte rows the two 16-lane groups of a 32-lane half (rows r..r+3 and
-//     r+4..r+7, same 32-byte half of the row) would meet on the same banks (2x per read), so each operand tile is stored as TWO
-//     PLANES of 32-byte rows (channels 0-15 / 16-31): one ds_read_b64_tr_b16 then covers 16 consecutive rows = 512 contiguous
-//     bytes for any tap offset -- conflict-free, and still lane base + immediate;
-//   * the DMA producers write 1 KiB pieces = 32 rows x 32 bytes of one plane (lane -> row lane>>1, 16-byte chunk lane&1);
-//   * k-step = 32 voxels (two x-rows of the 4x4x16 tile), 8 per tile, 4 MFMAs per tap and k-step into acc[tap][co half][ci half];
-//     accumulator lane layout: ci = 16 bh + (lane & 15), co = 16 ah + 4 (lane >> 4) + i.
-// ---------------------------------------------------------------------------------------------------------------------
-#define WGH16X_GPLANE (256 * 32)
-#define WGH16X_XPLANE (WGH16_HV * 32)
-#define WGH16X_XPIECES 11     // ceil(2 * 21 / 4): 21 one-KiB pieces per X plane (the last one 8 rows)
-
-template <typename T, int W>
-__device__ __forceinline__ void wgh16x_tile_mma(const lds_byte* gb, const lds_byte* xb, f32x4 (&acc)[7][2][2]) {
-  constexpr int NT = W < 3 ? 7 : 6;
-  u32x4 fa[2][2], fb[7][2];
-  auto read_a = [&](int s, int ah) { return tr_frag_at(gb, ah * WGH16X_GPLANE + s * 1024, ah * WGH16X_GPLANE + s * 1024 + 512); };
-  auto read_b = [&](int s, int j, int bh) {
-    const int vy = (2 * s) & 3, vz = s >> 1;
-    const int t = W + 4 * j;
-    const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;                   // 0..2 (the lane base sits at tap (-1,-1,-1))
-    const int off = bh * WGH16X_XPLANE + (((vz + dz) * WGH16_HY + (vy + dy)) * WGH16_HX + dx) * 32;
-    return tr_frag_at(xb, off, off + WGH16_HX * 32);
-  };
-#pragma unroll
-  for (int ah = 0; ah < 2; ++ah) fa[0][ah] = read_a(0, ah);
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int bh = 0; bh < 2; ++bh) fb[j][bh] = read_b(0, j, bh);
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    if (s + 1 < 8) {
-#pragma unroll
-      for (int ah = 0; ah < 2; ++ah) fa[(s + 1) & 1][ah] = read_a(s + 1, ah);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-#pragma unroll
-      for (int ah = 0; ah < 2; ++ah)
-#pragma unroll
-        for (int bh = 0; bh < 2; ++bh) Mma16<T>::run(acc[j][ah][bh], fa[s & 1][ah], fb[j][bh]);
-      if (s + 1 < 8) {
-#pragma unroll
-        for (int bh = 0; bh < 2; ++bh) fb[j][bh] = read_b(s + 1, j, bh);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(512, 1) void wgrad_halo16x_kernel(const T* __restrict__ gt, const T* __restrict__ xt, float* __restrict__ slab,
-                                                               float* __restrict__ dw, const WgHaloGeom g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x { G planes [2][256][16], X planes [2][648][16] }
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // 0-3 consumers, 4-7 producers
-  const int PPn = gridDim.x, lid = rx_xcd_remap(blockIdx.y * PPn + blockIdx.x, PPn * gridDim.y);
-  const int split = lid / PPn, pp = lid - split * PPn;
-  const int pr = pp / g.panels_c, pc = pp - pr * g.panels_c;
-  const int r0 = pr * 32, c0 = pc * 32;
-  const long xc0 = g.x_cs ? (long)pc * g.x_cs : (long)c0;
-  const int t_begin = split * g.tiles_per_split;
-  const int t_end = min(g.NT, t_begin + g.tiles_per_split);
-
-  f32x4 acc[7][2][2];
-  if (wave >= 4) {
-    // ================================= producers =================================
-    const int pw = wave - 4;
-    const int prow = lane >> 1, pch = (lane & 1) * 8;       // row inside a 32-row piece, element offset of the 16-byte chunk in its half
-    int xh[WGH16X_XPIECES], xdst[WGH16X_XPIECES], xco[WGH16X_XPIECES];
-#pragma unroll
-    for (int p = 0; p < WGH16X_XPIECES; ++p) {
-      const int k = 4 * p + pw;                              // piece: plane k / 21, rows 32 (k % 21) ..
-      const int bh = k >= 21 ? 1 : 0, rr = k - 21 * bh;
-      const int row = 32 * rr + prow;
-      const int hx = row % WGH16_HX, t = row / WGH16_HX;
-      xh[p] = (k < 42 && row < WGH16_HV) ? ((t / WGH16_HY) << 16) | ((t % WGH16_HY) << 8) | hx : -1;
-      xdst[p] = 2 * WGH16X_GPLANE + bh * WGH16X_XPLANE + rr * 1024;
-      xco[p] = 16 * bh + pch;
-    }
-    const unsigned OOB = 0x7fffff00u;
-    const long gbytes = (long)g.N * g.g_ss * 2, xbytes = ((long)g.N * g.x_ss + (g.x_cs ? (long)(g.Cc / 32 - 1) * g.x_cs : 0)) * 2;
-    __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)gt, 0, (unsigned)(gbytes > 0xfffffff0L ? 0xfffffff0L : gbytes), 0x00020000);
-    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)xt, 0, (unsigned)(xbytes > 0xfffffff0L ? 0xfffffff0L : xbytes), 0x00020000);
-    auto dma_tile = [&](int tile, int buf) {
-      int tx, ty, tz, n;
-      rx_tile_coords(tile, g.tx_n, g.ty_n, g.tz_n, g.order, n, tz, ty, tx);
-      const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
-      const unsigned gbase = (unsigned)((n * g.g_ss + r0 + pch) * 2);
-      const unsigned xbase = (unsigned)((n * g.x_ss + xc0) * 2);
-      __attribute__((address_space(3))) unsigned char* lB = (__attribute__((address_space(3))) unsigned char*)(smem + buf * WGH16_BUF_BYTES);
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int k = 4 * p + pw;                            // plane k >> 3, rows 32 (k & 7) ..
-        const int v = 32 * (k & 7) + prow;
-        const int z = z0 + (v >> 6), y = y0 + ((v >> 4) & 3), x = x0 + (v & 15);
-        const unsigned off = (z < g.Z && y < g.Y && x < g.X) ? gbase + (unsigned)((((z * g.Y + y) * g.X + x) * g.ldg + 16 * (k >> 3)) * 2) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, (__attribute__((address_space(3))) void*)(lB + 1024 * k), 16, off, 0, 0, 0);
-      }
-#pragma unroll
-      for (int p = 0; p < WGH16X_XPIECES; ++p) {
-        if (xh[p] >= 0) {
-          const int z = z0 + (xh[p] >> 16) - 1, y = y0 + ((xh[p] >> 8) & 255) - 1, x = x0 + (xh[p] & 255) - 1;
-          const bool ok = (unsigned)z < (unsigned)g.Z && (unsigned)y < (unsigned)g.Y && (unsigned)x < (unsigned)g.X;
-          const unsigned off = ok ? xbase + (unsigned)((((z * g.Y + y) * g.X + x) * g.ldx + xco[p]) * 2) : OOB;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)(lB + xdst[p]), 16, off, 0, 0, 0);
-        }
-      }
-    };
-    if (t_begin < t_end) dma_tile(t_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                   // tile 0 visible
-    for (int tile = t_begin; tile < t_end; ++tile) {
-      const int buf = (tile - t_begin) & 1;
-      if (tile + 1 < t_end) dma_tile(tile + 1, buf ^ 1);   // its readers passed the barrier that ended the previous iteration
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-  } else {
-    // ================================= consumers =================================
-#pragma unroll
-    for (int j = 0; j < 7; ++j)
-#pragma unroll
-      for (int ah = 0; ah < 2; ++ah)
-#pragma unroll
-        for (int bh = 0; bh < 2; ++bh) acc[j][ah][bh] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int kg = lane >> 4, l15 = lane & 15, q4 = l15 >> 2, p4 = l15 & 3;
-    const int lane_off = (4 * kg + q4) * 32 + p4 * 8;      // bytes inside a plane: voxel row 4 kg + q4, channel group 4 p4
-    auto run = [&](auto wc) {
-      constexpr int W = decltype(wc)::value;
-      __syncthreads();                                 // tile 0 visible
-      for (int tile = t_begin; tile < t_end; ++tile) {
-        const int buf = (tile - t_begin) & 1;
-        const lds_byte* gb = (const lds_byte*)(smem) + buf * WGH16_BUF_BYTES + lane_off;
-        if (!RX_ABLATE(g, 2)) wgh16x_tile_mma<T, W>(gb, gb + 2 * WGH16X_GPLANE, acc);
-        __syncthreads();
-      }
-    };
-    switch (wave) {
-      case 0: run(std::integral_constant<int, 0>{}); break;
-      case 1: run(std::integral_constant<int, 1>{}); break;
-      case 2: run(std::integral_constant<int, 2>{}); break;
-      default: run(std::integral_constant<int, 3>{}); break;
-    }
-  }
-
-  // ---- epilogue.  Accumulator element i of lane l in acc[j][ah][bh]: row (co) 16 ah + 4 (l >> 4) + i, column (ci) 16 bh + (l & 15)
-  const int ccol = lane & 15, rgrp = 4 * (lane >> 4);
-  if (g.S == 1) {
-    float* sT = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      __syncthreads();
-      if (wave < 4) {
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-          const int t = wave + 4 * j;
-          if (t < 27) {
-#pragma unroll
-            for (int bh = 0; bh < 2; ++bh)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) sT[((rgrp + i) * 32 + 16 * bh + ccol) * 27 + t] = acc[j][hb][bh][i];
-          }
-        }
-      }
-      __syncthreads();
-      for (int idx = tid; idx < 16 * 216; idx += 512) {
-        const int lr = idx / 216, i = idx - lr * 216;
-        *reinterpret_cast<f32x4*>(dw + ((long)(r0 + 16 * hb + lr) * g.Cc + c0) * 27 + 4 * i) = *reinterpret_cast<const f32x4*>(sT + 4 * idx);
-      }
-    }
-    return;
-  }
-  if (wave < 4) {
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      const int t = wave + 4 * j;
-      if (t < 27) {
-        float* out = slab + (((long)split * 27 + t) * g.R + r0) * g.Cc + c0;
-#pragma unroll
-        for (int ah = 0; ah < 2; ++ah)
-#pragma unroll
-          for (int bh = 0; bh < 2; ++bh)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) out[(long)(16 * ah + rgrp + i) * g.Cc + 16 * bh + ccol] = acc[j][ah][bh][i];
-      }
-    }
-  }
-}
-
 static int p2ceil(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -946,21 +748,10 @@ int rx_wgrad_halo_try(rx_dtype dt, const rx_act* x, const rx_act* dy, const int3
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
       attr16 = true;
     }
+    rx_note_kernel(ws_mode ? "wgrad_halo16ws_kernel" : "wgrad_halo16_kernel");
     const bool dma_ok = dma_mode && (long)g.N * g.g_ss * 2 < 0x7fffff00L &&
                         ((long)g.N * g.x_ss + (g.x_cs ? (long)(g.Cc / 32 - 1) * g.x_cs : 0)) * 2 < 0x7fffff00L;
-    static int m16 = -1;      // RX_WGH_M16=0: the 32x32x16 kernel
-    if (m16 < 0) {
-      const char* e = getenv("RX_WGH_M16");
-      m16 = e ? atoi(e) : 1;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16x_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds16));
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_halo16x_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds16));
-    }
-    rx_note_kernel(ws_mode && dma_ok && m16 ? "wgrad_halo16x_kernel" : ws_mode ? "wgrad_halo16ws_kernel" : "wgrad_halo16_kernel");
-    if (ws_mode && dma_ok && m16 && dt == RX_BF16)
-      hipLaunchKernelGGL((wgrad_halo16x_kernel<bf16_t>), grid, dim3(512), 2 * lds16, st, (const bf16_t*)dy->ptr, (const bf16_t*)x->ptr, (float*)ws, dw, g);
-    else if (ws_mode && dma_ok && m16)
-      hipLaunchKernelGGL((wgrad_halo16x_kernel<f16_t>), grid, dim3(512), 2 * lds16, st, (const f16_t*)dy->ptr, (const f16_t*)x->ptr, (float*)ws, dw, g);
-    else if (ws_mode && dma_ok && dt == RX_BF16)
+    if (ws_mode && dma_ok && dt == RX_BF16)
       hipLaunchKernelGGL((wgrad_halo16ws_kernel<bf16_t, true>), grid, dim3(512), 2 * lds16, st, (const bf16_t*)dy->ptr, (const bf16_t*)x->ptr, (float*)ws, dw, g);
     else if (ws_mode && dma_ok)
       hipLaunchKernelGGL((wgrad_halo16ws_kernel<f16_t, true>), grid, dim3(512), 2 * lds16, st, (const f16_t*)dy->ptr, (const f16_t*)x->ptr, (float*)ws, dw, g);

@@ -80,8 +80,8 @@ EXPECT_KERNELS = {
     (256, 256, (4, 4, 4), (3, 3, 3), (1, 1, 1)): ("igemm_fat_kernel", "igemm_fat_kernel", "wgrad_halo_kernel"),
     (512, 512, (4, 4, 4), (3, 3, 3), (1, 1, 1)): ("igemm_fat_kernel", "igemm_fat_kernel", "wgrad_halo_kernel"),
     (512, 512, (3, 8, 8), (3, 3, 3), (1, 1, 1)): ("igemm_fat_kernel", "igemm_fat_kernel", "wgrad_halo_kernel"),
-    (32, 32, (30, 36, 64), (3, 3, 3), (1, 1, 1)): ("conv_halo32p_kernel", "conv_halo32p_kernel", "wgrad_halo16x_kernel"),
-    (64, 64, (14, 32, 64), (3, 3, 3), (1, 1, 1)): ("conv_halo64ws_kernel", "conv_halo64ws_kernel", "wgrad_halo16x_kernel"),
+    (32, 32, (30, 36, 64), (3, 3, 3), (1, 1, 1)): ("conv_halo32p_kernel", "conv_halo32p_kernel", "wgrad_halo16ws_kernel"),
+    (64, 64, (14, 32, 64), (3, 3, 3), (1, 1, 1)): ("conv_halo64ws_kernel", "conv_halo64ws_kernel", "wgrad_halo16ws_kernel"),
     (128, 64, (32, 32, 64), (3, 3, 3), (2, 2, 2)): (None, "dgrad_s2p_kernel", None),
     (128, 64, (24, 40, 72), (3, 3, 3), (2, 2, 2)): (None, "dgrad_s2p_kernel", None),
     (64, 128, (12, 20, 18), (1, 1, 1), (1, 1, 1)): ("pointwise_kernel", "pointwise_kernel", None),
