@@ -168,8 +168,7 @@ class NetworkFromConfig(nn.Module):
 
         cd = model_config.get("compute_dtype", None)
         self.compute_dtype = _DTYPES[cd] if isinstance(cd, str) else cd   # None -> follow autocast
-        import weakref
-        object.__setattr__(self.shared_encoder, "_owner", weakref.ref(self))     # (not a submodule link: feature extraction hook)
+        self._bind_submodules()
         self._plans = {}
         self._weights_epoch = 0     # advanced by every backward: fused optimizers do not bump Tensor._version (engine/plan.py)
         if getattr(mgr, "verbose", False):
@@ -178,6 +177,25 @@ class NetworkFromConfig(nn.Module):
                   f"tasks={list(self.tasks)} ---")
 
     # ---- engine plumbing --------------------------------------------------------------------
+    def _bind_submodules(self):
+        """`model.shared_encoder(x)` / `model.task_decoders[t](skips)` run on this network's plans: the containers hold a weak
+        reference to their network (not a submodule link)."""
+        import weakref
+        object.__setattr__(self.shared_encoder, "_owner", weakref.ref(self))
+        for task_name in self.task_decoders.keys():
+            object.__setattr__(self.task_decoders[task_name], "_owner", weakref.ref(self))
+            object.__setattr__(self.task_decoders[task_name], "_task", task_name)
+
+    def __getstate__(self):          # copy.deepcopy / pickle: plans are launch lists over THIS object's tensors -- rebuilt on demand
+        st = dict(self.__dict__)
+        st["_plans"] = {}
+        return st
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._plans = {}
+        self._bind_submodules()      # a copy's containers must run on the copy, not on the original
+
     def _resolve_dtype(self):
         if self.compute_dtype is not None:
             return self.compute_dtype
@@ -228,6 +246,22 @@ class NetworkFromConfig(nn.Module):
         with torch.no_grad():
             plan = self.plan_for(x.shape, self._resolve_dtype(), x.device, False)
             return plan.run_encoder(x)
+
+    @torch.compiler.disable(recursive=True)
+    def decode(self, task_name, skips):
+        """one task decoder alone on a list of encoder outputs (reference decoder.py:137-162, `model.task_decoders[t](skips)`):
+        raw logits (the task activation is `NetworkFromConfig.forward`'s business upstream too), computed by the decoder part of
+        an inference plan (no autograd).  The input patch shape is the first stage's output times the first stage's stride."""
+        skips = list(skips)
+        s0 = skips[0]
+        if not s0.is_cuda:
+            raise _l.RxError("NetworkFromConfig runs only on an MI355X (gfx950) HIP device: got CPU tensors")
+        st0 = list(self.strides[0]) if isinstance(self.strides[0], (list, tuple)) else [self.strides[0]] * self.op_dims
+        shape = (s0.shape[0], self.in_channels, *[int(v) * int(k) for v, k in zip(s0.shape[2:], st0)])
+        names = list(self.task_decoders.keys())
+        with torch.no_grad():
+            plan = self.plan_for(torch.Size(shape), self._resolve_dtype(), s0.device, False)
+            return plan.run_decoder(names.index(task_name), task_name, skips)
 
     def _check_input(self, x):
         if not x.is_cuda:

@@ -65,6 +65,15 @@ class Decoder(EngineOnly):
         self.transpconvs = nn.ModuleList(ups)
         self.seg_layers = nn.ModuleList(heads)
 
+    def forward(self, skips):
+        """`model.task_decoders[task](skips)` as upstream (decoder.py:137-162): the task's raw logits from a list of encoder
+        outputs (lowest resolution last), computed by the decoder part of the owning network's plan on the HIP kernels, WITHOUT
+        autograd; a container that is not part of a NetworkFromConfig has nothing to run on."""
+        owner = self._owner() if getattr(self, "_owner", None) is not None else None
+        if owner is None or self._task not in owner.task_decoders or owner.task_decoders[self._task] is not self:
+            return super().forward(skips)
+        return owner.decode(self._task, skips)
+
     def compute_conv_feature_map_size(self, input_size):
         skip_sizes = []
         for s in range(len(self.encoder.strides) - 1):

@@ -86,7 +86,7 @@ class Encoder(EngineOnly):
         network's plan on the HIP kernels, WITHOUT autograd (the training path goes through the whole network: one engine call
         owns forward and backward); a container that is not part of a NetworkFromConfig has nothing to run on."""
         owner = self._owner() if getattr(self, "_owner", None) is not None else None
-        if owner is None:
+        if owner is None or owner.shared_encoder is not self:      # (a copy of the container alone does not run on the original)
             return super().forward(x)
         skips = owner.encode(x)
         return skips if self.return_skips else skips[-1]

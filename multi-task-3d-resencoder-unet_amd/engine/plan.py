@@ -620,9 +620,12 @@ class Plan:
         P = self
         f = self.fwd
         self.n_fwd_enc = None                 # number of forward steps that belong to the encoder tape (run_encoder)
+        self.fwd_dec_start = []               # first forward step of each decoder tape (run_decoder)
         for tape in [self.enc_tape] + self.dec_tapes:
             if tape is not self.enc_tape and self.n_fwd_enc is None:
                 self.n_fwd_enc = len(f)
+            if tape is not self.enc_tape:
+                self.fwd_dec_start.append(len(f))
             # conv -> InstanceNorm pairs whose statistics can come out of the conv epilogue (rx_conv3d_fwd_stats): 3x3x3
             # stride-1 layers in a 16-bit compute type, above the size the single-launch InstanceNorm kernel takes
             for i, rec in enumerate(tape[:-1]):
@@ -1400,6 +1403,37 @@ class Plan:
             outs.append(t.squeeze(2) if self.two_d else t)
         self.generation += 1
         return outs
+
+    def run_decoder(self, d, name, skips):
+        """one task decoder alone (eager launches) on caller-supplied encoder outputs: `skips` = the list `run_encoder` returns (NCDHW,
+        one tensor per stage, real channel counts).  They are written into the plan's stage-output buffers (channels-last compute
+        type, padded channels zero), then the decoder's part of the forward list runs; returns the raw logits (decoder.py:137-162)."""
+        if len(skips) != len(self.enc_skips):
+            raise ValueError(f"expected {len(self.enc_skips)} encoder outputs, got {len(skips)}")
+        self._apply_act = False
+        self._forward_pre()
+        self.refresh_packs(force=False)
+        self._issue_deferred_packs()
+        for ent in self.packs:
+            self._await_pack(ent)
+        for (at, c), t in zip(self.enc_skips, skips):
+            t = t.detach()
+            if self.two_d:
+                t = t.unsqueeze(2)
+            want = (self.B, c, *at.act.dims[1:4])
+            if tuple(t.shape) != want:
+                raise ValueError(f"encoder output of shape {tuple(t.shape)} where the plan holds {want}")
+            act = at.act                     # (a channel view of its buffer: stage outputs may live inside a concat)
+            act.t[..., act.c0:act.c0 + c].copy_(t.permute(0, 2, 3, 4, 1))
+            if act.c > c:
+                act.t[..., act.c0 + c:act.c0 + act.c].zero_()
+        a = self.fwd_dec_start[d]
+        b = self.fwd_dec_start[d + 1] if d + 1 < len(self.fwd_dec_start) else len(self.fwd)
+        for step in self.fwd[a:b]:
+            step()
+        self.generation += 1
+        v = self.outputs[name]
+        return (v.squeeze(2) if self.two_d else v).clone()
 
     def _backward_body(self):
         self._dy_free.clear()       # the previous backward ended with the side stream joined: nothing is still read

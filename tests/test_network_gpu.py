@@ -648,7 +648,31 @@ def test_shared_encoder_is_callable_on_its_own(NetworkFromConfig, case):
     for k, v in ev.items():
         assert rel_l2(v.cpu(), g[f"eval.{k}"]) < 2e-4, k
     import copy
-    bare = copy.deepcopy(net.shared_encoder)
-    object.__setattr__(bare, "_owner", None)
+    bare = copy.deepcopy(net.shared_encoder)      # a copy of the container alone is not part of any network
     with pytest.raises(RuntimeError):
         bare(x)
+    # ... and the decoders likewise (decoder.py:137-162): encoder outputs in, the task's raw logits out -- the same bits as the
+    # whole network's logits, since the outputs handed over are exactly what the plan held
+    logits = net.forward_logits(x)
+    for name in net.task_decoders.keys():
+        dl = net.task_decoders[name](got)
+        assert dl.dtype == torch.float32 and torch.equal(dl, logits[name]), name
+    with pytest.raises(RuntimeError):
+        copy.deepcopy(net.task_decoders[name])(got)
+    with pytest.raises(ValueError):
+        net.task_decoders[name](got[:-1])
+    # a deep copy of the NETWORK runs its containers on the copy's own weights
+    twin = copy.deepcopy(net)
+    with torch.no_grad():
+        for q in twin.parameters():
+            q.mul_(0.5)
+    t_sk = twin.shared_encoder(x)
+    assert not torch.equal(t_sk[-1], got[-1])
+    assert torch.equal(twin.task_decoders[name](t_sk), twin.forward_logits(x)[name])
+    assert torch.equal(net.shared_encoder(x)[-1], got[-1])
+    # 16-bit plans (planar concat buffers at full resolution, fused head kernels): same contract
+    net.compute_dtype = torch.bfloat16
+    sk16 = net.shared_encoder(x)
+    lg16 = net.forward_logits(x)
+    for name in net.task_decoders.keys():
+        assert torch.equal(net.task_decoders[name](sk16), lg16[name]), name
