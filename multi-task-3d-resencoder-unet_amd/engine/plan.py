@@ -212,11 +212,14 @@ class Plan:
         return [1] + v if self.two_d else v
 
     def _check_extent(self, numel, name):
-        # kernels index elements (and some of them bytes) with 32 bits; the largest size exercised on hardware is 2^31 bytes
-        # per tensor (scripts/big_patch_check.py: 256^3, batch 2, 32 channels, bf16) -- beyond that refuse instead of risking a fault
-        if numel * self.dtype.itemsize > (1 << 31):
-            raise UnsupportedConfig(f"activation tensor {name} would have {numel} elements ({numel * self.dtype.itemsize} bytes > 2^31): "
-                                    "lower the batch or patch size")
+        # the kernels address a SAMPLE with 32-bit element (some: byte) offsets and step from sample to sample with 64-bit strides
+        # (`ptr + (long)n * sample_stride`; the LDS-DMA variants, whose buffer descriptors span the whole tensor, step aside above
+        # 2^31 bytes per tensor): the cap is 2^31 bytes PER SAMPLE of a tensor.  Exercised on hardware: 256^3 x 32 channels bf16 at
+        # batch 2 (2^31 bytes per tensor) and batch 3 (3.2 GB per tensor), scripts/big_patch_check.py
+        per_sample = numel // max(self.B, 1)
+        if per_sample * self.dtype.itemsize > (1 << 31):
+            raise UnsupportedConfig(f"activation tensor {name} would have {per_sample} elements per sample "
+                                    f"({per_sample * self.dtype.itemsize} bytes > 2^31): lower the patch size")
 
     def _new(self, dims, c, name, ld=None, needs_grad=True):
         self._check_extent(self.B * dims[0] * dims[1] * dims[2] * (ld or c), name)
@@ -236,7 +239,7 @@ class Plan:
                   and os.environ.get("RX_PLANAR_CAT", "1") != "0")
         if not planar:
             return self._new(dims, 2 * c, name, ld=2 * c)
-        self._check_extent(2 * self.B * vox * 32, name)
+        self._check_extent(self.B * vox * 32, name)       # per PLANE: the two planes are separate dense tensors (rx_act.cs is 64-bit)
         root = torch.empty((2, self.B, *dims, 32), dtype=self.dtype, device=self.device)
         self.bytes_alloc += root.numel() * root.element_size()
         return AT(Act.planar(root), name)

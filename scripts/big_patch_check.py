@@ -41,6 +41,16 @@ for n in g1:
 if B > 1:
     o3, l3, g3 = run(x.flip(0).contiguous(), t.flip(0).contiguous())
     assert torch.equal(o3.flip(0), o1), "sample independence (batch swap) violated"
+if B > 2:      # tensors beyond 2^31 bytes: every sample alone (a batch-1 plan, far below the limit) must give the batch's logits
+    net.eval()
+    with torch.no_grad():
+        whole = net(x)["sheet"]
+        for i in range(B):
+            one = net(x[i:i + 1].contiguous())["sheet"]
+            d = (one - whole[i:i + 1]).abs().max().item()
+            print(f"sample {i} alone vs in the batch: max |diff| {d:.3e}", flush=True)
+            assert d <= 1e-2 * whole.abs().max().item(), (i, d)
+    net.train()
 opt = torch.optim.SGD(net.parameters(), lr=0.05)
 losses = []
 for _ in range(3):

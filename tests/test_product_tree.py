@@ -171,9 +171,11 @@ def test_reference_task_files_behave_as_upstream():
 
 
 def test_oversized_activation_is_refused_before_any_launch():
-    """kernels index with 32 bits in places: the plan refuses a tensor beyond the largest extent exercised on hardware (2^30
-    elements: 256^3 x 32 channels x batch 2, scripts/big_patch_check.py) instead of risking a device fault"""
-    mgr = oracle.make_mgr((320, 320, 320), {"a": {"channels": 1}}, 1, 2, True, {})
+    """kernels address a SAMPLE of a tensor with 32 bits (and step between samples with 64): the plan refuses a tensor with more than
+    2^31 bytes per sample instead of risking a device fault; the batch does not count (scripts/big_patch_check.py ran 256^3 at batch 4)"""
+    mgr = oracle.make_mgr((384, 384, 384), {"a": {"channels": 1}}, 1, 1, True, {})
     with pytest.raises(UnsupportedConfig):
-        Plan(NetworkFromConfig(mgr).to("meta"), (2, 1, 320, 320, 320), torch.bfloat16, "meta", True)
+        Plan(NetworkFromConfig(mgr).to("meta"), (1, 1, 384, 384, 384), torch.bfloat16, "meta", True)
+    mgr = oracle.make_mgr((256, 256, 256), {"a": {"channels": 1}}, 1, 4, True, {})
+    Plan(NetworkFromConfig(mgr).to("meta"), (4, 1, 256, 256, 256), torch.bfloat16, "meta", True)       # 4.3 GB per tensor: fine
     Plan(NetworkFromConfig(mgr).to("meta"), (1, 1, 256, 256, 256), torch.bfloat16, "meta", False)      # fine
