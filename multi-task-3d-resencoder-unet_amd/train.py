@@ -82,6 +82,47 @@ class PinnedRingCollate:
             self.events[self.last] = ev
 
 
+class DeviceFeeder:
+    """Iterates a DataLoader one batch AHEAD of the consumer: the host-to-device copies of batch i+1 are enqueued on a copy stream
+    while step i computes, and the compute stream only waits for their event.  On the main stream (the reference's
+    `batch["image"].to(device)`, train.py:199-203) the 33.5 MB of a cfg2 batch sit between two steps: 0.7 ms of a 17 ms step with
+    the device idle (`scripts/step_timeline.py` on a `--through-trainer` trace: first kernel 707 us after the previous step's last)."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, device
+        self.stream = torch.cuda.Stream(device)
+        ring = getattr(loader, "collate_fn", None)
+        self.ring = ring if isinstance(ring, PinnedRingCollate) else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, it):
+        try:
+            batch = next(it)
+        except StopIteration:
+            return None
+        with torch.cuda.stream(self.stream):
+            dev = {k: v.to(self.device, dtype=torch.float32, non_blocking=True) for k, v in batch.items()}
+            if self.ring is not None:
+                self.ring.copied()          # (records on the copy stream: the pinned slot is free once THESE copies are done)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return dev, ev
+
+    def __iter__(self):
+        it = iter(self.loader)
+        nxt = self._stage(it)
+        while nxt is not None:
+            dev, ev = nxt
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for t in dev.values():
+                t.record_stream(cur)        # allocated on the copy stream, consumed on the compute stream
+            yield dev                       # the consumer enqueues its step ...
+            nxt = self._stage(it)           # ... and only then does the host collate and copy the next batch, under that step
+
+
 class BaseTrainer:
     def __init__(self, config_file: str, verbose: bool = True, debug_dataloader: bool = False):
         self.mgr = ConfigManager(config_file, verbose=verbose)
@@ -231,10 +272,11 @@ class BaseTrainer:
                    if isinstance(engine_model, NetworkFromConfig) and os.environ.get("RX_STREAMED_STEP", "0") == "1" else None)
 
         def forward_loss(batch, train_mode):
+            staged = batch["image"].is_cuda          # a DeviceFeeder batch: already on the device, its pinned slot already released
             x = batch["image"].to(device, dtype=torch.float32, non_blocking=True)
             targets = {k: v.to(device, dtype=torch.float32, non_blocking=True) for k, v in batch.items() if k != "image"}
             ring = getattr(train_loader, "collate_fn", None)
-            if train_mode and isinstance(ring, PinnedRingCollate):
+            if train_mode and not staged and isinstance(ring, PinnedRingCollate):
                 ring.copied()               # the pinned slot may be refilled once these copies are done
             with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
                 out = model(x)
@@ -256,7 +298,9 @@ class BaseTrainer:
             steps, patches = 0, 0
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
-            for i, batch in enumerate(train_loader):
+            feeder = (DeviceFeeder(train_loader, device)
+                      if device.type == "cuda" and os.environ.get("RX_DEVICE_FEEDER", "1") != "0" else train_loader)
+            for i, batch in enumerate(feeder):
                 if i >= self.mgr.max_steps_per_epoch:
                     break
                 total, per, bsz = forward_loss(batch, True)
