@@ -120,3 +120,39 @@ def test_training_from_zarr_volumes_with_squeeze_excite(tmp_path):
     assert any("squeeze_excitation.fc1.weight" in k for k in model.state_dict())
     assert len(tr.losses) == 3 and tr.losses[-1] < tr.losses[0]
     assert os.path.exists(tmp_path / "cache" / "zarr_se_32_32_32_cache.json")
+
+
+@pytest.mark.gpu
+def test_device_feeder_hands_over_the_loaders_batches_in_order():
+    """`DeviceFeeder` (one batch ahead on a copy stream, pinned ring slots released by the copy stream's event) must be invisible:
+    the same batches, in order, as float32 device tensors; ring slots are reused (more batches than slots) without corrupting a
+    batch that has not been consumed yet; breaking out early leaves nothing hanging."""
+    import mt3d_amd  # noqa: F401
+    from torch.utils.data import DataLoader, Dataset
+    from mt3d_amd.train import DeviceFeeder, PinnedRingCollate
+
+    class Items(Dataset):
+        def __len__(self):
+            return 23
+
+        def __getitem__(self, i):
+            g = torch.Generator().manual_seed(i)
+            return {"image": torch.randn((1, 8, 16, 16), generator=g), "sheet": (torch.rand((1, 8, 16, 16), generator=g) > 0.5).to(torch.uint8)}
+
+    ds = Items()
+    want = list(DataLoader(ds, batch_size=2, shuffle=False))
+    loader = DataLoader(ds, batch_size=2, shuffle=False, collate_fn=PinnedRingCollate(depth=3), pin_memory=False)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    got = []
+    for b in DeviceFeeder(loader, dev):
+        assert all(v.is_cuda and v.dtype == torch.float32 for v in b.values())
+        got.append({k: v.clone() for k, v in b.items()})
+        torch.cuda._sleep(2_000_000)          # the consumer is slow: the feeder is a batch ahead, the ring wraps around meanwhile
+    assert len(got) == len(want) == 12
+    for a, w in zip(got, want):
+        for k in w:
+            assert torch.equal(a[k].cpu(), w[k].float()), k
+    for i, b in enumerate(DeviceFeeder(loader, dev)):
+        if i == 2:
+            break
+    torch.cuda.synchronize()
