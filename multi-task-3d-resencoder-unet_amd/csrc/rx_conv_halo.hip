@@ -705,7 +705,15 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
 #define CH64_W_BYTES (9 * 64 * 64)
 #define CH64_X_BYTES (648 * 64)
 
-template <typename T, bool FLIP, bool GLDS, bool XDMA = false, bool STATS = false, bool ACC = false>
+// BSP (data-gradient launches that COMPLETE the output gradient of an InstanceNorm layer without residual -- see ConvHaloGeom::bs_y):
+// the layer's two backward sums come out of this launch.  The consumer waves have no registers to spare for them (conv_halo32p keeps
+// them there), so they go to the PRODUCER waves, which idle between DMA issues: a tile's output is staged in LDS as bf16 (the halo
+// buffer of the tile's last chunk is free from the barrier that ends the tile until the DMA issued in the next tile's second phase;
+// 144-byte voxel rows), the consumers read it back for whole-row 16-byte global stores, the producers read it once more, beside the
+// layer's y (fetched during the tile's last phase), and keep running sums of g' and g' * (y - mean) for 8 channels per thread; one
+// partial row per producer wave at the end, laid out like ch_stat_flush's.  One more barrier per tile; alone the staging is neutral
+// (DESIGN 10.4 row bf).
+template <typename T, bool FLIP, bool GLDS, bool XDMA = false, bool STATS = false, bool ACC = false, bool BSP = false>
 __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
                                                                T* __restrict__ out, const ConvHaloGeom g, int tiles_per_wg) {
   constexpr int P = Elem<T>::PER16;
@@ -846,13 +854,55 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
       }
     };
     if (XDMA) {
+      // ---- BSP: this thread's share of the backward sums: 16-byte chunk bc (8 channels) of voxels bvg + 32 p of every tile
+      const int bc = ptid & 7, bvg = ptid >> 3;
+      float bs1[8], bs2[8], bmean[8];
+      u32x4 yv[8];
+      if (BSP) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bs1[j] = 0.f, bs2[j] = 0.f, bmean[j] = g.bs_stats[2 * ((size_t)sn * g.Co + n0 + 8 * bc + j)];
+      }
+      auto bs_load_y = [&](int tile) {
+        int n, z0, y0, x0;
+        tile_origin(tile, n, z0, y0, x0);
+        const T* yp = (const T*)g.bs_y + (long)n * g.bs_yss + n0 + 8 * bc;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          const int v = bvg + 32 * p;
+          const int z = z0 + (v >> 6), y = y0 + ((v >> 4) & 3), x = x0 + (v & 15);
+          yv[p] = (z < g.Z && y < g.Y && x < g.X) ? *reinterpret_cast<const u32x4*>(yp + ((long)(z * g.Y + y) * g.X + x) * g.bs_ldy) : u32x4{0u, 0u, 0u, 0u};
+        }
+      };
+      auto bs_accumulate = [&](int tile, const unsigned char* sS) {
+        int n, z0, y0, x0;
+        tile_origin(tile, n, z0, y0, x0);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          const int v = bvg + 32 * p;
+          const int z = z0 + (v >> 6), y = y0 + ((v >> 4) & 3), x = x0 + (v & 15);
+          if (z < g.Z && y < g.Y && x < g.X) {
+            const u32x4 gq = *reinterpret_cast<const u32x4*>(sS + v * 144 + bc * 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float gg = Elem<T>::to_f(reinterpret_cast<const T*>(&gq)[j]);          // the gradient as stored
+              const float yc = Elem<T>::to_f(reinterpret_cast<const T*>(&yv[p])[j]) - bmean[j];
+              if (!(yc > 0.f)) gg *= g.bs_slope;
+              bs1[j] += gg;
+              bs2[j] += gg * yc;
+            }
+          }
+        }
+      };
       if (nphase > 0) {
         dma_weights(0);
         dma_halo(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       lds_only_barrier();
+      int pit = 0, pending = -1;             // pending: tile whose staged output waits for bs_accumulate
+      const unsigned char* pendS = nullptr;
       for (int ph = 0; ph < nphase; ++ph) {
+        const bool tile_end = pit == ppt - 1;
         if (ph + 1 < nphase) {
           dma_weights(ph + 1);
           if (ph + 2 < nphase && (ph + 2) % 3 == 0) {
@@ -865,10 +915,47 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
             else
               asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
           } else {
+            // (a tile's first phase, behind this phase's DMA issue: the previous tile's staged output is still in its halo buffer --
+            // the DMA that overwrites it is issued in the NEXT iteration; a tile's last phase: fetch its y for the sums)
+            if (BSP && pending >= 0) {
+              bs_accumulate(pending, pendS);
+              pending = -1;
+            }
+            if (BSP && tile_end) bs_load_y(t_begin + ph / ppt);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           }
+        } else if (BSP) {                      // the workgroup's very last phase
+          bs_load_y(t_begin + ph / ppt);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         lds_only_barrier();
+        if (++pit == ppt) {
+          pit = 0;
+          if (BSP) {                           // the consumers stage the tile between this barrier and the next one
+            lds_only_barrier();
+            pending = t_begin + ph / ppt;
+            pendS = sXb + ((ph / 3) & 1) * CH64_X_BYTES;
+          }
+        }
+      }
+      if (BSP) {
+        if (pending >= 0) bs_accumulate(pending, pendS);
+        // lanes 8 vg + bc of a wave hold the same 8 channels: fold the 8 voxel groups, one partial row per producer wave
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float u = bs1[j], v = bs2[j];
+#pragma unroll
+          for (int o = 8; o < 64; o <<= 1) {
+            u += __shfl_xor(u, o, 64);
+            v += __shfl_xor(v, o, 64);
+          }
+          bs1[j] = u, bs2[j] = v;
+        }
+        if (pl < 8) {
+          float* p0 = g.stat_part + ((size_t)(sn * (g.wgs_s * 4) + sl * 4 + pw) * 2) * g.Co + n0 + 8 * pl;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) p0[j] = bs1[j], p0[g.Co + j] = bs2[j];
+        }
       }
     } else {
     if (nphase > 0) {
@@ -997,12 +1084,18 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
           ++ph;
         }
       }
-      // ---- epilogue of this tile (its stores stay in flight), then the barrier that ends the tile's last phase
+      // ---- epilogue of this tile (its stores stay in flight), then the barrier that ends the tile's last phase.  BSP: the tile
+      // goes through LDS (see the kernel's header): barrier, stage, barrier, whole-row stores
       int n, z0, y0, x0;
       tile_origin(tile, n, z0, y0, x0);
+      constexpr int SROW = 144;
+      unsigned char* sS = sXb + ((ph / 3) & 1) * CH64_X_BYTES;
+      if (BSP) lds_only_barrier();
+      int fv2 = fv;
+      if (BSP) asm volatile("" : "+v"(fv2));      // (recomputed per tile: hoisted out of the tile loop the staging addresses cost spills)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const int v = (wave * 2 + b) * 32 + fv;
+        const int v = (wave * 2 + b) * 32 + fv2;
         const int z = z0 + (v >> 6), y = y0 + ((v >> 4) & 3), x = x0 + (v & 15);
         if (z >= g.Z || y >= g.Y || x >= g.X || RX_ABLATE(g, 8)) continue;
         T* op = out + (long)n * g.out_ss + ((long)(z * g.Y + y) * g.X + x) * g.ldo + n0;
@@ -1030,12 +1123,28 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
                   s2[a][4 * g4 + i] += r * r;
                 }
               }
-              if (!RX_ABLATE(g, 16) || vals[0] == (T)12345.f) *reinterpret_cast<u32x2*>(op + cm) = *reinterpret_cast<u32x2*>(vals);
+              if (BSP) *reinterpret_cast<u32x2*>(sS + v * SROW + co * 2) = *reinterpret_cast<u32x2*>(vals);
+              else if (!RX_ABLATE(g, 16) || vals[0] == (T)12345.f) *reinterpret_cast<u32x2*>(op + cm) = *reinterpret_cast<u32x2*>(vals);
             }
         };
         RX_EPI_DISPATCH(bias != nullptr, !ACC && g.accumulate != 0, epi);
       }
       lds_only_barrier();
+      if (BSP) {
+        // piece i = tid + 256 p of the tile: voxel (tid >> 3) + 32 p = (z p>>1, y (tid>>7) + 2 (p&1), x (tid>>3)&15), 16-byte chunk tid & 7
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        const int ry = t2 >> 7, rx = (t2 >> 3) & 15, c = t2 & 7;
+        T* gp = out + (long)n * g.out_ss + ((long)(z0 * g.Y + y0 + ry) * g.X + x0 + rx) * g.ldo + n0 + (c >> 2) * g.out_cs + (c & 3) * 8;
+        const unsigned char* lp = sS + (t2 >> 3) * SROW + c * 16;
+        const bool okx = x0 + rx < g.X;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          const int zz = p >> 1, yy = 2 * (p & 1);
+          if (okx && z0 + zz < g.Z && y0 + ry + yy < g.Y)
+            *reinterpret_cast<u32x4*>(gp + ((long)(zz * g.Y + yy) * g.X) * g.ldo) = *reinterpret_cast<const u32x4*>(lp + p * 32 * SROW);
+        }
+      }
       ++ph;
     }
     if (STATS) ch_stat_flush<2>(s1, s2, g.stat_part, sn, g.wgs_s * 4, sl * 4 + wave, g.Co, n0, lane);
@@ -1077,7 +1186,8 @@ static void ch64ws_launch(hipStream_t st, const void* in, const void* w, const f
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  if (glds && xdma && g.stat_part && !g.flip && (long)g.N * g.in_ss * 2 < 0x7fffff00L) {
+  const bool dma_ok = glds && xdma && (long)g.N * g.in_ss * 2 < 0x7fffff00L;   // (out-of-range offsets must stay out of range of the descriptor)
+  if (dma_ok && g.stat_part && !g.flip && !g.bs_y) {
     static bool attr_s = false;
     if (!attr_s) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, false, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1086,7 +1196,22 @@ static void ch64ws_launch(hipStream_t st, const void* in, const void* w, const f
     hipLaunchKernelGGL((conv_halo64ws_kernel<T, false, true, true, true>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
     return;
   }
-  const_cast<ConvHaloGeom&>(g).stat_part = nullptr;              // only the instantiation above accumulates statistics
+  if (dma_ok && g.bs_y && g.stat_part && g.flip && !((uintptr_t)out & 15) && g.ldo % 8 == 0 && g.out_cs % 8 == 0 && !((uintptr_t)g.bs_y & 15) &&
+      g.bs_ldy % 8 == 0) {     // backward sums on the producer waves (whole-row 16-byte stores / loads)
+    static bool attr_b = false;
+    if (!attr_b) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, true, true, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, true, true, true, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_b = true;
+    }
+    if (g.accumulate)
+      hipLaunchKernelGGL((conv_halo64ws_kernel<T, true, true, true, false, true, true>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
+    else
+      hipLaunchKernelGGL((conv_halo64ws_kernel<T, true, true, true, false, false, true>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
+    return;
+  }
+  const_cast<ConvHaloGeom&>(g).bs_y = nullptr;                   // (not taken: the caller runs the separate reduce pass)
+  const_cast<ConvHaloGeom&>(g).stat_part = nullptr;              // only the instantiations above accumulate statistics
   if (glds && xdma && g.accumulate && g.flip && (long)g.N * g.in_ss * 2 < 0x7fffff00L) {     // dx +=: old values prefetched
     static bool attr_a = false;
     if (!attr_a) {
@@ -1379,8 +1504,19 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
       const char* e = getenv("RX_CH64_STATS");
       st64 = e ? atoi(e) : 1;
     }
-    const bool fuse64 = st64 && stat_part && stat_chunks && !flip && !accumulate && (size_t)g.N * 1024 * 2 * g.Co * sizeof(float) <= stat_bytes;
-    g.stat_part = fuse64 ? stat_part : nullptr;
+    const bool room64 = stat_part && stat_chunks && (size_t)g.N * 1024 * 2 * g.Co * sizeof(float) <= stat_bytes;
+    static int bs64 = -1;    // RX_CH64_BWD_STATS=0: no backward sums out of this kernel
+    if (bs64 < 0) {
+      const char* e = getenv("RX_CH64_BWD_STATS");
+      bs64 = e ? atoi(e) : 1;
+    }
+    const bool fuse64 = st64 && room64 && !flip && !accumulate && !bs;
+    const bool fuse64b = bs64 && room64 && flip && bs;
+    g.stat_part = (fuse64 || fuse64b) ? stat_part : nullptr;
+    if (fuse64b) {
+      g.bs_y = bs->y->ptr, g.bs_ldy = bs->y->ld, g.bs_yss = rx_act_voxels(bs->y) * (long)bs->y->ld;
+      g.bs_stats = bs->stats, g.bs_slope = bs->slope;
+    }
     if (dt == RX_BF16)
       ch64ws_launch<bf16_t>(st, in->ptr, w, bias, out->ptr, g);
     else
@@ -1391,7 +1527,8 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
       return RX_ELAUNCH;
     }
     if (fuse64 && g.stat_part) *stat_chunks = g.wgs_s * 4;      // (the launcher clears stat_part when it took a variant without them)
-    g.stat_part = nullptr;
+    if (fuse64b && g.bs_y && g.stat_part) *stat_chunks = g.wgs_s * 4;
+    g.stat_part = nullptr, g.bs_y = nullptr;
     return 1;
   }
   if (in->cs || out->cs) RX_FAIL(RX_EUNSUPPORTED, "conv_halo: planar-concat operand on the generic halo kernel");

@@ -910,7 +910,7 @@ class Plan:
                                 a["head_dw_fused"] = True
                                 gw[1]["dw_fused"] = True
                     if (gw[0] == "conv" and a["gate"] is None and res is None and self.dtype != torch.float32
-                            and out.act.full_buffer and out.act.root is None and out.act.c == 32 and out.act.voxels > 512
+                            and out.act.full_buffer and out.act.root is None and out.act.c % 32 == 0 and out.act.voxels > 512
                             and out.act.dims[3] >= 16 and os.environ.get("RX_FUSED_BWD_STATS", "1") != "0"):
                         a["m12"] = torch.empty((self.B, out.act.c, 2), dtype=torch.float32, device=self.device)
                         a["m12_valid"] = False

@@ -477,10 +477,13 @@ def test_planar_concat_convs_equal_interleaved(ops, dtype):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("slope", [0.01, 1.0])
 @pytest.mark.parametrize("accumulate", [False, True])
-def test_conv3d_bwd_data_instats(ops, dtype, slope, accumulate):
+@pytest.mark.parametrize("c,dims", [(32, (30, 36, 64)),      # >= 512 tiles of 4x4x16, ragged z / y: conv_halo32p (sums on the consumer waves)
+                                    (64, (14, 30, 64)),      # conv_halo64ws: sums on the producer waves out of the LDS-staged tile, ragged z / y
+                                    (128, (14, 32, 64))])    # two channel blocks per tile
+def test_conv3d_bwd_data_instats(ops, dtype, slope, accumulate, c, dims):
     """rx_conv3d_bwd_data_instats: same dx as rx_conv3d_bwd_data bit for bit, and (mean g', mean g'*xhat) of the InstanceNorm
     layer it completes equal to the two-pass reduction over the stored dx (fp64 on the host)"""
-    n, c, dims = 3, 32, (30, 36, 64)                       # >= 512 tiles of 4x4x16, ragged z / y: the persistent kernel
+    n = 3
     dyv = to_act(ops, rnd((n, c, *dims), dtype, seed=1, scale=0.2), dtype)
     w = rnd((c, c, 3, 3, 3), torch.float32, seed=2, scale=0.1).float().cuda()
     _, wb = ops.pack_conv_weight(w, dtype)
@@ -494,7 +497,7 @@ def test_conv3d_bwd_data_instats(ops, dtype, slope, accumulate):
     ops.conv3d_bwd_data(dyv, wb, dx1, k, s, accumulate)
     fused = ops.conv3d_bwd_data_instats(dyv, wb, dx2, k, s, accumulate, yv, stats, slope, m12)
     torch.cuda.synchronize()
-    assert fused, "the 32 -> 32 layer with >= 512 tiles must take the persistent kernel"
+    assert fused, "these layers must take a persistent kernel that delivers the sums"
     assert torch.equal(dx1.t, dx2.t)
     g = dx1.to_ncdhw().double().cpu()
     y = yv.to_ncdhw().double().cpu()
