@@ -713,18 +713,25 @@ __global__ __launch_bounds__(512, 1) void conv_halo32p_kernel(const T* __restric
 // layer's y (fetched during the tile's last phase), and keep running sums of g' and g' * (y - mean) for 8 channels per thread; one
 // partial row per producer wave at the end, laid out like ch_stat_flush's.  One more barrier per tile; alone the staging is neutral
 // (DESIGN 10.4 row bf).
-template <typename T, bool FLIP, bool GLDS, bool XDMA = false, bool STATS = false, bool ACC = false, bool BSP = false>
+// NA: 32-channel output blocks per workgroup (2: the 64-channel block this kernel was written for; 1: layers whose (tile, 64-channel
+// block) pairs would leave CUs idle -- 256 channels at 16^3 -- run as (tile, 32-channel block) pairs: half the weight plane per phase,
+// half the MFMAs, the same halo; LDS-DMA variants only).
+template <typename T, bool FLIP, bool GLDS, bool XDMA = false, bool STATS = false, bool ACC = false, bool BSP = false, int NA = 2>
 __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
                                                                T* __restrict__ out, const ConvHaloGeom g, int tiles_per_wg) {
   constexpr int P = Elem<T>::PER16;
   constexpr int KB = 4 * P;
   constexpr int TZ = 4, TY = 4, TX = 16, HY = TY + 2, HX = TX + 2, HV = 648;
   constexpr int XPIECES = (HV * 4 + 255) / 256;   // 11
-  constexpr int WPIECES = 9 * 64 * 4 / 256;       // 9
+  static_assert(NA == 2 || (GLDS && XDMA && !BSP), "32-channel blocks: LDS-DMA variants without backward sums only");
+  constexpr int BNW = 32 * NA;                    // output channels per workgroup
+  constexpr int W_BYTES = 9 * BNW * 64;           // one weight plane
+  constexpr int WINSTR = 9 * BNW / 16;            // 1-KiB DMA pieces of a plane (18 / 9 per 4 producer waves)
+  constexpr int WPIECES = (WINSTR + 3) / 4;       // 9 (NA = 2) / 5, the last one on two waves only (NA = 1)
   constexpr int CENTRE = HY * HX + HX + 1;        // 127
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sWb = smem;                        // [2][9*64][64 B]
-  unsigned char* sXb = smem + 2 * CH64_W_BYTES;     // [2][648][64 B]
+  unsigned char* sXb = smem + 2 * W_BYTES;          // [2][648][64 B]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -734,7 +741,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
   const int NTs = g.NT / g.N;                          // tiles per sample
   const int sn = g.wgs_s ? vb / g.wgs_s : 0, sl = g.wgs_s ? vb - sn * g.wgs_s : 0;
   if (g.wgs_s) t_begin = sn * NTs + sl * tiles_per_wg, t_end = min((sn + 1) * NTs, t_begin + tiles_per_wg);
-  const int n0 = (lid - vb * gridDim.y) * 64;
+  const int n0 = (lid - vb * gridDim.y) * BNW;
   const int nchunks = g.Ci / KB;
   const int ppt = 3 * nchunks;                      // phases per tile
   const int nphase = (t_end - t_begin) * ppt;
@@ -759,7 +766,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
 #pragma unroll
     for (int p = 0; p < WPIECES; ++p) {
       const int i = ptid + 256 * p;                  // piece ((tl*64 + r)*4 + c4)
-      const int c4 = i & 3, r = (i >> 2) & 63, tl = i >> 8;
+      const int c4 = i & 3, r = (i >> 2) % BNW, tl = (i >> 2) / BNW;
       woff[p] = ((tl * g.Co + n0 + r) * g.Ci) + c4 * P;
     }
     const long wplane = (long)9 * g.Co * g.Ci;
@@ -770,8 +777,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
     int goff[WPIECES];
 #pragma unroll
     for (int p = 0; p < WPIECES; ++p) {
-      const int rr = (p * 4 + pw) * 16 + (pl >> 2);        // tl*64 + r
-      const int tl = rr >> 6, r = rr & 63, c4 = (pl & 3) ^ ((rr >> 2) & 3);
+      const int rr = (p * 4 + pw) * 16 + (pl >> 2);        // tl*BNW + r
+      const int tl = rr / BNW, r = rr % BNW, c4 = (pl & 3) ^ ((rr >> 2) & 3);
       goff[p] = ((tl * g.Co + n0 + r) * g.Ci) + c4 * P;
     }
     u32x4 xr[XPIECES], wr[WPIECES];
@@ -780,9 +787,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
       const int r = ph % ppt, cc = r / 3, dzg = r - cc * 3;
       const T* wp = w + dzg * wplane + cc * KB;
       __attribute__((address_space(3))) unsigned char* dst =
-          (__attribute__((address_space(3))) unsigned char*)(sWb + (ph & 1) * CH64_W_BYTES);
+          (__attribute__((address_space(3))) unsigned char*)(sWb + (ph & 1) * W_BYTES);
 #pragma unroll
       for (int p = 0; p < WPIECES; ++p)
+        if (p * 4 + pw < WINSTR)              // (wave-uniform; the counted waits below only count the halo pieces issued after these)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + goff[p]),
                                          (__attribute__((address_space(3))) void*)(dst + (p * 4 + pw) * 1024), 16, 0, 0);
     };
@@ -792,13 +800,13 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
     // rows >= 648 in the last piece are switched off.  No staging registers, no ds_write pass.
     const int schunk = (pl & 3) ^ ((pl >> 4) & 3);
     __amdgpu_buffer_rsrc_t rX;
-    if (XDMA) rX = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (unsigned)((long)g.N * g.in_ss * 2), 0x00020000);
+    if (XDMA) rX = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (unsigned)(((long)g.N * g.in_ss + (g.in_cs == KB ? 0L : (long)(g.Ci / KB - 1) * g.in_cs)) * 2), 0x00020000);   // (planar concat: plane j at j * in_cs)
     auto dma_halo = [&](int ph) {
       if (RX_ABLATE(g, 1)) return;
       const int tile = t_begin + ph / ppt, cc = (ph % ppt) / 3;
       int n, z0, y0, x0;
       tile_origin(tile, n, z0, y0, x0);
-      const unsigned base = (unsigned)(((long)n * g.in_ss + cc * KB + schunk * P) * 2);
+      const unsigned base = (unsigned)(((long)n * g.in_ss + cc * g.in_cs + schunk * P) * 2);     // (in_cs == KB unless the input is a planar concat)
       __attribute__((address_space(3))) unsigned char* dst =
           (__attribute__((address_space(3))) unsigned char*)(sXb + ((ph / 3) & 1) * CH64_X_BYTES);
 #pragma unroll
@@ -821,7 +829,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
       if (dzg == 0) {
         int n, z0, y0, x0;
         tile_origin(tile, n, z0, y0, x0);
-        const T* in_n = in + (long)n * g.in_ss + cc * KB + chunk * P;
+        const T* in_n = in + (long)n * g.in_ss + cc * g.in_cs + chunk * P;
 #pragma unroll
         for (int p = 0; p < XPIECES; ++p) {
           u32x4 v = u32x4{0u, 0u, 0u, 0u};
@@ -835,7 +843,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
       }
     };
     auto commit_phase = [&](int ph) {
-      unsigned char* sW = sWb + (ph & 1) * CH64_W_BYTES;
+      unsigned char* sW = sWb + (ph & 1) * W_BYTES;
       if (!GLDS) {
 #pragma unroll
         for (int p = 0; p < WPIECES; ++p) {
@@ -1004,11 +1012,11 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
     const unsigned sW_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)sWb;
     const unsigned sX_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)sXb;
 
-    f32x16 acc[2][2];
+    f32x16 acc[NA][2];
     auto plane = [&](auto dzc, unsigned wbase, unsigned xbase) {
       constexpr int DZG = decltype(dzc)::value;
       constexpr int DEPTH = STATS ? 2 : 3;      // the 64 statistics accumulators leave room for a 3-slot fragment ring only
-      u32x4 fa[DEPTH + 1][2], fb[DEPTH + 1][2];
+      u32x4 fa[DEPTH + 1][NA], fb[DEPTH + 1][2];
       unsigned xa[2];
       auto ld = [&](int i, int slot) {
         const int tl = i >> 1, ks = i & 1;
@@ -1019,7 +1027,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
           for (int b = 0; b < 2; ++b) xa[b] = xbase + xorg[b] + K * 64 + (((swt[b] >> (2 * (K & 15))) & 3u) << 4);
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a) fa[slot][a] = *(const lds_u32x4*)(uintptr_t)(wbase + (ks ? wl1 : wl0) + (tl * 64 + a * 32) * 64);
+        for (int a = 0; a < NA; ++a) fa[slot][a] = *(const lds_u32x4*)(uintptr_t)(wbase + (ks ? wl1 : wl0) + (tl * BNW + a * 32) * 64);
 #pragma unroll
         for (int b = 0; b < 2; ++b) fb[slot][b] = *(const lds_u32x4*)(uintptr_t)(ks ? xa[b] ^ 32u : xa[b]);
       };
@@ -1031,24 +1039,24 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
         if (i + DEPTH < 18) ld(i + DEPTH, (i + DEPTH) % (DEPTH + 1));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
           for (int b = 0; b < 2; ++b) Mma<T>::run(acc[a][b], fa[i % (DEPTH + 1)][a], fb[i % (DEPTH + 1)][b]);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
 
-    float s1[2][16], s2[2][16];
+    float s1[NA][16], s2[NA][16];
     if (STATS) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s1[a][r] = 0.f, s2[a][r] = 0.f;
     }
     lds_only_barrier();
     int ph = 0;
     for (int tile = t_begin; tile < t_end; ++tile) {
-      u32x2 oldv[2][2][4];                               // accumulate: old dx values fetched under the MFMA loops (see conv_halo32p)
+      u32x2 oldv[NA][2][4];                               // accumulate: old dx values fetched under the MFMA loops (see conv_halo32p)
       if (ACC) {
         int n_, z0_, y0_, x0_;
         tile_origin(tile, n_, z0_, y0_, x0_);
@@ -1059,26 +1067,26 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
           const bool ok = z < g.Z && y < g.Y && x < g.X;
           const T* op = out + (long)n_ * g.out_ss + ((long)(z * g.Y + y) * g.X + x) * g.ldo + n0 + 4 * fh;
 #pragma unroll
-          for (int a = 0; a < 2; ++a)
+          for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) oldv[a][b][g4] = ok ? *reinterpret_cast<const u32x2*>(op + a * g.out_cs + 8 * g4) : u32x2{0u, 0u};
         }
       }
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
       for (int cc = 0; cc < nchunks; ++cc) {
         const unsigned xbase = sX_base + ((ph / 3) & 1) * CH64_X_BYTES;
-        if (!RX_ABLATE(g, 4)) plane(std::integral_constant<int, 0>{}, sW_base + (ph & 1) * CH64_W_BYTES, xbase);
+        if (!RX_ABLATE(g, 4)) plane(std::integral_constant<int, 0>{}, sW_base + (ph & 1) * W_BYTES, xbase);
         lds_only_barrier();
         ++ph;
-        if (!RX_ABLATE(g, 4)) plane(std::integral_constant<int, 1>{}, sW_base + (ph & 1) * CH64_W_BYTES, xbase);
+        if (!RX_ABLATE(g, 4)) plane(std::integral_constant<int, 1>{}, sW_base + (ph & 1) * W_BYTES, xbase);
         lds_only_barrier();
         ++ph;
-        if (!RX_ABLATE(g, 4)) plane(std::integral_constant<int, 2>{}, sW_base + (ph & 1) * CH64_W_BYTES, xbase);
+        if (!RX_ABLATE(g, 4)) plane(std::integral_constant<int, 2>{}, sW_base + (ph & 1) * W_BYTES, xbase);
         if (cc + 1 < nchunks) {
           lds_only_barrier();
           ++ph;
@@ -1101,7 +1109,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
         T* op = out + (long)n * g.out_ss + ((long)(z * g.Y + y) * g.X + x) * g.ldo + n0;
         auto epi = [&](auto HB, auto RA) {
 #pragma unroll
-          for (int a = 0; a < 2; ++a)
+          for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
               const int co = a * 32 + 8 * g4 + 4 * fh;
@@ -1147,7 +1155,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo64ws_kernel(const T* __restri
       }
       ++ph;
     }
-    if (STATS) ch_stat_flush<2>(s1, s2, g.stat_part, sn, g.wgs_s * 4, sl * 4 + wave, g.Co, n0, lane);
+    if (STATS) ch_stat_flush<NA>(s1, s2, g.stat_part, sn, g.wgs_s * 4, sl * 4 + wave, g.Co, n0, lane);
   }
 }
 
@@ -1235,6 +1243,44 @@ static void ch64ws_launch(hipStream_t st, const void* in, const void* w, const f
     hipLaunchKernelGGL((conv_halo64ws_kernel<T, true, false>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
   else
     hipLaunchKernelGGL((conv_halo64ws_kernel<T, false, false>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per);
+}
+
+// the 32-channel-block instantiations (NA = 1) of conv_halo64ws: LDS-DMA only.  Returns false (nothing launched) when the DMA
+// preconditions do not hold -- the caller then takes conv_halo32_kernel as before.
+template <typename T>
+static bool ch32ws_launch(hipStream_t st, const void* in, const void* w, const float* bias, void* out, const ConvHaloGeom& g) {
+  const size_t lds = (size_t)2 * (9 * 32 * 64 + CH64_X_BYTES);
+  if (!(((long)g.N * g.in_ss + (g.in_cs == 32 ? 0L : (long)(g.Ci / 32 - 1) * g.in_cs)) * 2 < 0x7fffff00L)) return false;   // (planar concat input: the planes lie in_cs apart)
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, false, true, true, false, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, false, true, true, true, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, true, true, true, false, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64ws_kernel<T, true, true, true, false, true, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const int cob = g.Co / 32;
+  int wgs = 256 / cob;                                   // one persistent workgroup per CU in total
+  if (wgs < 1) wgs = 1;
+  if (wgs > g.NT) wgs = g.NT;
+  const int NTs = g.NT / g.N;                            // a workgroup's tile range never straddles samples
+  int wgs_s = wgs / g.N > 0 ? wgs / g.N : 1;
+  const int per = (NTs + wgs_s - 1) / wgs_s;
+  wgs_s = (NTs + per - 1) / per;
+  wgs = wgs_s * g.N;
+  const_cast<ConvHaloGeom&>(g).wgs_s = wgs_s;
+  dim3 grid(wgs, cob);
+#define RX_32WS(F, S, A) hipLaunchKernelGGL((conv_halo64ws_kernel<T, F, true, true, S, A, false, 1>), grid, dim3(512), lds, st, (const T*)in, (const T*)w, bias, (T*)out, g, per)
+  if (g.stat_part && !g.flip && !g.accumulate) {
+    RX_32WS(false, true, false);
+    return true;
+  }
+  const_cast<ConvHaloGeom&>(g).stat_part = nullptr;
+  if (g.flip && g.accumulate) RX_32WS(true, false, true);
+  else if (g.flip) RX_32WS(true, false, false);
+  else RX_32WS(false, false, false);
+#undef RX_32WS
+  return true;
 }
 
 template <typename T>
@@ -1467,6 +1513,33 @@ int rx_conv_halo_try(rx_dtype dt, const rx_act* in, const void* w, const float* 
   }
   ConvHaloGeom g1 = g;                                // one tile per workgroup: bricks of tiles where the tile grid allows
   if (g.order && g.tx_n % 4 == 0 && g.ty_n % 4 == 0 && g.tz_n % 4 == 0) g1.order = 2;
+  if (BN == 32 && TZ == 4 && TY == 4 && TX == 16 && dt != RX_F32 && !out->cs && g.Ci >= 64 && (long)g.NT * (g.Co / 32) >= 256 &&
+      !(accumulate && !flip)) {
+    // 32-channel blocks on the wave-specialised DMA pipeline (the 256-channel layers at 16^3: 32 tiles x 8 blocks = one workgroup
+    // per CU; alone 43 -> ~30 us against conv_halo32_kernel's one tile per workgroup)
+    static int ws32 = -1;     // RX_CH32WS=0: conv_halo32_kernel
+    if (ws32 < 0) {
+      const char* e = getenv("RX_CH32WS");
+      ws32 = e ? atoi(e) : 1;
+    }
+    if (ws32) {
+      const bool fuse = stat_part && stat_chunks && !flip && !accumulate && (size_t)g.N * 1024 * 2 * g.Co * sizeof(float) <= stat_bytes;
+      ConvHaloGeom g2 = g;
+      g2.stat_part = fuse ? stat_part : nullptr;
+      g2.bs_y = nullptr;
+      const bool launched = dt == RX_BF16 ? ch32ws_launch<bf16_t>(st, in->ptr, w, bias, out->ptr, g2) : ch32ws_launch<f16_t>(st, in->ptr, w, bias, out->ptr, g2);
+      if (launched) {
+        rx_note_kernel("conv_halo32ws_kernel");
+        hipError_t e7 = hipGetLastError();
+        if (e7 != hipSuccess) {
+          rx_set_error("conv_halo32ws: %s", hipGetErrorString(e7));
+          return RX_ELAUNCH;
+        }
+        if (fuse && g2.stat_part) *stat_chunks = g2.wgs_s * 4;
+        return 1;
+      }
+    }
+  }
   if (BN == 32 && TZ == 4 && TY == 4 && TX == 16) {  // full-resolution layers: compile-time tile, padded rows
     if (out->cs) RX_FAIL(RX_EUNSUPPORTED, "conv_halo32: planar-concat output");
     rx_note_kernel("conv_halo32_kernel");

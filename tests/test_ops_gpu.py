@@ -70,6 +70,7 @@ CONV_CASES = [
     (32, 32, (9, 9, 12), (7, 3, 5), (2, 1, 3)),       # everything different
     (32, 32, (8, 9, 10), (2, 4, 6), (1, 2, 2)),       # even kernel sizes: pad (k-1)//2 is asymmetric, the output shrinks
     (32, 32, (8, 8, 8), (1, 1, 1), (2, 2, 2)),        # kernel narrower than the stride: 7 of the 8 classes of dx have no tap (zeros)
+    (64, 96, (14, 32, 32), (3, 3, 3), (1, 1, 1)),     # 128 ragged tiles x 3 (fwd) / 2 (dgrad) 32-channel blocks: the 32-channel-block DMA pipeline
 ]
 
 
@@ -82,6 +83,7 @@ EXPECT_KERNELS = {
     (512, 512, (3, 8, 8), (3, 3, 3), (1, 1, 1)): ("igemm_fat_kernel", "igemm_fat_kernel", "wgrad_halo_kernel"),
     (32, 32, (30, 36, 64), (3, 3, 3), (1, 1, 1)): ("conv_halo32p_kernel", "conv_halo32p_kernel", "wgrad_halo16ws_kernel"),
     (64, 64, (14, 32, 64), (3, 3, 3), (1, 1, 1)): ("conv_halo64ws_kernel", "conv_halo64ws_kernel", "wgrad_halo16ws_kernel"),
+    (64, 96, (14, 32, 32), (3, 3, 3), (1, 1, 1)): ("conv_halo32ws_kernel", "conv_halo32ws_kernel", None),
     (128, 64, (32, 32, 64), (3, 3, 3), (2, 2, 2)): (None, "dgrad_s2p_kernel", None),
     (128, 64, (24, 40, 72), (3, 3, 3), (2, 2, 2)): (None, "dgrad_s2p_kernel", None),
     (64, 128, (12, 20, 18), (1, 1, 1), (1, 1, 1)): ("pointwise_kernel", "pointwise_kernel", None),
